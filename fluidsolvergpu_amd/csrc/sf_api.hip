@@ -1,0 +1,889 @@
+// sf_api.hip — host side of libsfgpu.so: contexts, slab decomposition, halo exchange, the step
+// sequences of docs/SPEC.md §3 and the C ABI of include/sfgpu.h.
+//
+// Structure (MI355X-first, not a translation of the reference's host loop, solver.cu:171-216):
+//   * one context = L logical k-slabs of one process on one GPU; P = nranks*L slabs in total.
+//     Each slab has a compute stream and a halo stream. An operator is launched first on the two
+//     slab-boundary planes, then on the interior planes; the halo stream ships the boundary planes
+//     (device-to-device copy between slabs of the same process, RCCL send/recv grouped over xGMI
+//     between processes) while the interior sweep runs. No collective reduction exists anywhere in
+//     the step, only neighbour exchange.
+//   * fields are named slots holding device pointers, so SPEC's "swap" is a pointer swap.
+//   * there is NO CPU fallback: without a gfx950 device sf_create fails with SF_ERR_NO_DEVICE.
+#include "../../include/sfgpu.h"
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "sf_kernels.hpp"
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct Failure {
+    int code;
+    std::string msg;
+};
+
+#define SF_HIP(expr)                                                                               \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess)                                                                      \
+            throw Failure{SF_ERR_HIP, std::string("Error ") + hipGetErrorString(_e) + " at line " + \
+                                          std::to_string(__LINE__) + " in file " + __FILE__ +      \
+                                          " (" #expr ")"};                                         \
+    } while (0)
+
+#define SF_NCCL(expr)                                                                              \
+    do {                                                                                           \
+        ncclResult_t _r = (expr);                                                                  \
+        if (_r != ncclSuccess)                                                                     \
+            throw Failure{SF_ERR_RCCL, std::string("RCCL error ") + ncclGetErrorString(_r) +       \
+                                           " at line " + std::to_string(__LINE__) + " (" #expr ")"}; \
+    } while (0)
+
+#define SF_REQUIRE(cond, text)                                          \
+    do {                                                                \
+        if (!(cond)) throw Failure{SF_ERR_INVALID, std::string(text)};  \
+    } while (0)
+
+inline int env_int(const char* name, int dflt) {
+    const char* s = std::getenv(name);
+    return (s && *s) ? std::atoi(s) : dflt;
+}
+
+inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+class SolverBase {
+public:
+    virtual ~SolverBase() {}
+    virtual void upload(int field, const void* host) = 0;
+    virtual void download(int field, void* host) = 0;
+    virtual void download_planes(int field, int kb, int ke, void* host) = 0;
+    virtual void owned_planes(int* kb, int* ke) const = 0;
+    virtual void fill(int field, double value) = 0;
+    virtual void copy_field(int dst, int src) = 0;
+    virtual void vel_step() = 0;
+    virtual void dens_step() = 0;
+    virtual void add_source(int x, int s) = 0;
+    virtual void set_bnd(int b, int x) = 0;
+    virtual void lin_solve(int b, int x, int x0, double a, double c, int iters) = 0;
+    virtual void diffuse(int b, int x, int x0, double diff) = 0;
+    virtual void advect(int b, int d, int d0, int u, int v, int w) = 0;
+    virtual void project(int u, int v, int w, int p, int div) = 0;
+    virtual void set_iters(int iters) = 0;
+    virtual void set_coefficients(double dt, double diff, double visc) = 0;
+    virtual void sync() = 0;
+    virtual void timer_start() = 0;
+    virtual float timer_stop() = 0;
+    virtual double copy_bandwidth(size_t bytes, int reps) = 0;
+    virtual void layout_info(int* pitch, int* planes, size_t* bytes) const = 0;
+};
+
+template <class T>
+class Solver final : public SolverBase {
+    static constexpr int W = sfk::VecT<T>::W;
+    static constexpr int NSCRATCH = 3;
+
+    struct Slab {
+        int gid = 0;  // global slab index 0..P-1
+        sfk::Geom geom{};
+        T* field[SF_NUM_FIELDS] = {};
+        T* scratch[NSCRATCH] = {};
+        hipStream_t cs = nullptr;  // compute
+        hipStream_t hs = nullptr;  // halo
+        hipEvent_t boundary_done = nullptr;
+        hipEvent_t halo_done = nullptr;
+        int* d_flag = nullptr;
+    };
+
+public:
+    explicit Solver(const sf_params& p) : N_(p.N), K_(p.iters), device_(p.device) {
+        SF_REQUIRE(p.N >= 1, "N must be >= 1");
+        SF_REQUIRE(p.iters >= 0, "iters must be >= 0");
+        L_ = p.nslabs_local > 0 ? p.nslabs_local : 1;
+        nranks_ = p.nranks > 0 ? p.nranks : 1;
+        rank_ = p.rank;
+        SF_REQUIRE(rank_ >= 0 && rank_ < nranks_, "rank out of range");
+        P_ = nranks_ * L_;
+        SF_REQUIRE(N_ % P_ == 0, "N must be divisible by nranks*nslabs_local");
+        SF_REQUIRE(nranks_ == 1 || p.nccl_id != nullptr, "nccl_id required when nranks > 1");
+        set_coefficients(p.dt, p.diff, p.visc);
+
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+            throw Failure{SF_ERR_NO_DEVICE, "no HIP device visible: libsfgpu has no CPU fallback"};
+        SF_REQUIRE(device_ >= 0 && device_ < ndev, "device ordinal out of range");
+        SF_HIP(hipSetDevice(device_));
+        hipDeviceProp_t prop;
+        SF_HIP(hipGetDeviceProperties(&prop, device_));
+        if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0 && !env_int("SF_ALLOW_ANY_ARCH", 0))
+            throw Failure{SF_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName +
+                                                ", this library is built for gfx950 only"};
+        num_cu_ = prop.multiProcessorCount;
+
+        // layout
+        nzl_ = N_ / P_;
+        lead_ = 128 / (int)sizeof(T);
+        const int line = 128 / (int)sizeof(T);
+        px_ = ceil_div(lead_ + N_ + 1 + W, line) * line;
+        plane_ = (long)px_ * (N_ + 2);
+        nplanes_ = nzl_ + 2;
+        field_elems_ = plane_ * nplanes_ + 256;  // slack so whole-vector accesses never leave the buffer
+        field_elems_ = (field_elems_ + W - 1) / W * W;
+
+        slabs_.resize(L_);
+        for (int s = 0; s < L_; ++s) {
+            Slab& sl = slabs_[s];
+            sl.gid = rank_ * L_ + s;
+            sl.geom.N = N_;
+            sl.geom.nzl = nzl_;
+            sl.geom.kg0 = sl.gid * nzl_;  // first interior k = gid*nzl + 1
+            sl.geom.px = px_;
+            sl.geom.lead = lead_;
+            sl.geom.plane = plane_;
+            sl.geom.wall_lo = (sl.gid == 0);
+            sl.geom.wall_hi = (sl.gid == P_ - 1);
+            SF_HIP(hipStreamCreateWithFlags(&sl.cs, hipStreamNonBlocking));
+            SF_HIP(hipStreamCreateWithFlags(&sl.hs, hipStreamNonBlocking));
+            SF_HIP(hipEventCreateWithFlags(&sl.boundary_done, hipEventDisableTiming));
+            SF_HIP(hipEventCreateWithFlags(&sl.halo_done, hipEventDisableTiming));
+            for (int f = 0; f < SF_USER0; ++f) sl.field[f] = alloc_field();
+            for (int f = 0; f < NSCRATCH; ++f) sl.scratch[f] = alloc_field();
+            SF_HIP(hipMalloc(&sl.d_flag, sizeof(int)));
+            SF_HIP(hipMemset(sl.d_flag, 0, sizeof(int)));
+        }
+        SF_HIP(hipEventCreate(&t0_));
+        SF_HIP(hipEventCreate(&t1_));
+        if (nranks_ > 1) {
+            ncclUniqueId id;
+            static_assert(sizeof(ncclUniqueId) <= SF_NCCL_ID_BYTES, "ncclUniqueId larger than ABI slot");
+            std::memcpy(&id, p.nccl_id, sizeof id);
+            SF_NCCL(ncclCommInitRank(&comm_, nranks_, id, rank_));
+        }
+        kchunk_ = env_int("SF_KCHUNK", 0);
+        SF_HIP(hipDeviceSynchronize());
+    }
+
+    ~Solver() override {
+        (void)hipSetDevice(device_);
+        (void)hipDeviceSynchronize();
+        if (comm_) ncclCommDestroy(comm_);
+        for (Slab& sl : slabs_) {
+            for (T*& f : sl.field)
+                if (f) (void)hipFree(f);
+            for (T*& f : sl.scratch)
+                if (f) (void)hipFree(f);
+            if (sl.d_flag) (void)hipFree(sl.d_flag);
+            if (sl.cs) (void)hipStreamDestroy(sl.cs);
+            if (sl.hs) (void)hipStreamDestroy(sl.hs);
+            if (sl.boundary_done) (void)hipEventDestroy(sl.boundary_done);
+            if (sl.halo_done) (void)hipEventDestroy(sl.halo_done);
+        }
+        if (t0_) (void)hipEventDestroy(t0_);
+        if (t1_) (void)hipEventDestroy(t1_);
+        if (copy_src_) (void)hipFree(copy_src_);
+        if (copy_dst_) (void)hipFree(copy_dst_);
+    }
+
+    // ---- host <-> device ------------------------------------------------------------------
+    void upload(int field, const void* host) override {
+        check_field(field);
+        SF_REQUIRE(host != nullptr, "null host pointer");
+        SF_HIP(hipSetDevice(device_));
+        const size_t S = (size_t)N_ + 2;
+        for (Slab& sl : slabs_) {
+            T* dev = ensure(sl, field);
+            // every stored plane (ghosts included) comes from the global array
+            const int kg_first = sl.geom.kg0;  // local plane 0
+            const T* src = static_cast<const T*>(host) + (size_t)kg_first * S * S;
+            SF_HIP(hipMemcpy2DAsync(dev + (lead_ - 1), (size_t)px_ * sizeof(T), src, S * sizeof(T),
+                                    S * sizeof(T), S * (size_t)nplanes_, hipMemcpyHostToDevice, sl.cs));
+        }
+        for (Slab& sl : slabs_) SF_HIP(hipStreamSynchronize(sl.cs));
+    }
+
+    void download(int field, void* host) override {
+        check_field(field);
+        SF_REQUIRE(host != nullptr, "null host pointer");
+        for (Slab& sl : slabs_) {
+            const int kb = sl.geom.kg0 + 1 - (sl.geom.wall_lo ? 1 : 0);
+            const int ke = sl.geom.kg0 + nzl_ + 1 + (sl.geom.wall_hi ? 1 : 0);
+            const size_t S = (size_t)N_ + 2;
+            copy_planes_out(sl, field, kb, ke, static_cast<T*>(host) + (size_t)kb * S * S);
+        }
+        for (Slab& sl : slabs_) SF_HIP(hipStreamSynchronize(sl.cs));
+    }
+
+    void download_planes(int field, int kb, int ke, void* host) override {
+        check_field(field);
+        SF_REQUIRE(host != nullptr, "null host pointer");
+        SF_REQUIRE(kb < ke, "empty plane range");
+        const size_t S = (size_t)N_ + 2;
+        bool any = false;
+        for (Slab& sl : slabs_) {
+            // planes of [kb,ke) this slab is the owner of (interior; shell planes on wall slabs)
+            const int ob = sl.geom.kg0 + 1 - (sl.geom.wall_lo ? 1 : 0);
+            const int oe = sl.geom.kg0 + nzl_ + 1 + (sl.geom.wall_hi ? 1 : 0);
+            const int b = std::max(kb, ob), e = std::min(ke, oe);
+            if (b >= e) continue;
+            any = true;
+            copy_planes_out(sl, field, b, e, static_cast<T*>(host) + (size_t)(b - kb) * S * S);
+        }
+        SF_REQUIRE(any, "plane range not stored by this context");
+        for (Slab& sl : slabs_) SF_HIP(hipStreamSynchronize(sl.cs));
+    }
+
+    void owned_planes(int* kb, int* ke) const override {
+        if (kb) *kb = slabs_.front().geom.kg0 + 1;
+        if (ke) *ke = slabs_.back().geom.kg0 + nzl_ + 1;
+    }
+
+    void fill(int field, double value) override {
+        check_field(field);
+        SF_HIP(hipSetDevice(device_));
+        for (Slab& sl : slabs_) {
+            T* dev = ensure(sl, field);
+            const long nvec = field_elems_ / W;
+            hipLaunchKernelGGL((sfk::fill_kernel<T>), dim3(stream_grid(nvec)), dim3(256), 0, sl.cs, dev,
+                               (T)value, nvec);
+        }
+        SF_HIP(hipGetLastError());
+    }
+
+    void copy_field(int dst, int src) override {
+        check_field(dst);
+        check_field(src);
+        SF_REQUIRE(dst != src, "copy_field: dst == src");
+        SF_HIP(hipSetDevice(device_));
+        for (Slab& sl : slabs_) {
+            T* d = ensure(sl, dst);
+            T* s = ensure(sl, src);
+            SF_HIP(hipMemcpyAsync(d, s, (size_t)field_elems_ * sizeof(T), hipMemcpyDeviceToDevice, sl.cs));
+        }
+    }
+
+    // ---- operators ------------------------------------------------------------------------
+    void add_source(int x, int s) override {
+        check_field(x);
+        check_field(s);
+        SF_HIP(hipSetDevice(device_));
+        const int xs[1] = {x}, ss[1] = {s};
+        op_add_source<1>(xs, ss);
+    }
+
+    void set_bnd(int b, int x) override {
+        check_field(x);
+        check_b(b);
+        SF_HIP(hipSetDevice(device_));
+        for (Slab& sl : slabs_) {
+            T* dev = ensure(sl, x);
+            const long n0 = std::max((long)N_ * nzl_, (long)N_ * N_);
+            const long n1 = std::max(N_, nzl_);
+            hipLaunchKernelGGL((sfk::set_bnd_kernel<T>), dim3((unsigned)((n0 + 255) / 256)), dim3(256), 0,
+                               sl.cs, sl.geom, dev, b, 0);
+            hipLaunchKernelGGL((sfk::set_bnd_kernel<T>), dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0,
+                               sl.cs, sl.geom, dev, b, 1);
+            hipLaunchKernelGGL((sfk::set_bnd_kernel<T>), dim3(1), dim3(64), 0, sl.cs, sl.geom, dev, b, 2);
+        }
+        SF_HIP(hipGetLastError());
+        if (P_ > 1) {
+            for (Slab& sl : slabs_) SF_HIP(hipEventRecord(sl.boundary_done, sl.cs));
+            const int fs[1] = {x};
+            exchange<1>(fs);
+        }
+    }
+
+    void lin_solve(int b, int x, int x0, double a, double c, int iters) override {
+        check_field(x);
+        check_field(x0);
+        check_b(b);
+        SF_REQUIRE(x != x0, "lin_solve: x and x0 must be different fields");
+        SF_REQUIRE(iters >= 0, "iters must be >= 0");
+        SF_HIP(hipSetDevice(device_));
+        const int xs[1] = {x}, x0s[1] = {x0}, bs[1] = {b};
+        op_lin_solve<1>(xs, x0s, bs, (T)a, (T)c, iters);
+    }
+
+    void diffuse(int b, int x, int x0, double diff) override {
+        check_field(x);
+        check_field(x0);
+        check_b(b);
+        SF_REQUIRE(x != x0, "diffuse: x and x0 must be different fields");
+        SF_HIP(hipSetDevice(device_));
+        const int xs[1] = {x}, x0s[1] = {x0}, bs[1] = {b};
+        const T a = diffusion_a((T)diff);
+        op_lin_solve<1>(xs, x0s, bs, a, T(1) + T(6) * a, K_);
+    }
+
+    void advect(int b, int d, int d0, int u, int v, int w) override {
+        check_field(d);
+        check_field(d0);
+        check_field(u);
+        check_field(v);
+        check_field(w);
+        check_b(b);
+        SF_REQUIRE(d != d0 && d != u && d != v && d != w, "advect: output must not alias an input");
+        SF_HIP(hipSetDevice(device_));
+        const int ds[1] = {d}, d0s[1] = {d0}, bs[1] = {b};
+        op_advect<1>(ds, d0s, bs, u, v, w);
+    }
+
+    void project(int u, int v, int w, int p, int div) override {
+        const int all[5] = {u, v, w, p, div};
+        for (int a = 0; a < 5; ++a) {
+            check_field(all[a]);
+            for (int c = a + 1; c < 5; ++c) SF_REQUIRE(all[a] != all[c], "project: fields must be distinct");
+        }
+        SF_HIP(hipSetDevice(device_));
+        op_project(u, v, w, p, div);
+    }
+
+    // SPEC §3 vel_step.
+    void vel_step() override {
+        SF_HIP(hipSetDevice(device_));
+        const int vel[3] = {SF_U, SF_V, SF_W}, vel0[3] = {SF_U0, SF_V0, SF_W0}, b123[3] = {1, 2, 3};
+        op_add_source<3>(vel, vel0);
+        swap_slots(SF_U0, SF_U);
+        swap_slots(SF_V0, SF_V);
+        swap_slots(SF_W0, SF_W);
+        const T a = diffusion_a(visc_);
+        op_lin_solve<3>(vel, vel0, b123, a, T(1) + T(6) * a, K_);
+        op_project(SF_U, SF_V, SF_W, SF_U0, SF_V0);
+        swap_slots(SF_U0, SF_U);
+        swap_slots(SF_V0, SF_V);
+        swap_slots(SF_W0, SF_W);
+        op_advect<3>(vel, vel0, b123, SF_U0, SF_V0, SF_W0);
+        op_project(SF_U, SF_V, SF_W, SF_U0, SF_V0);
+    }
+
+    // SPEC §3 dens_step.
+    void dens_step() override {
+        SF_HIP(hipSetDevice(device_));
+        const int x[1] = {SF_DENS}, x0[1] = {SF_DENS0}, b0[1] = {0};
+        op_add_source<1>(x, x0);
+        swap_slots(SF_DENS0, SF_DENS);
+        const T a = diffusion_a(diff_);
+        op_lin_solve<1>(x, x0, b0, a, T(1) + T(6) * a, K_);
+        swap_slots(SF_DENS0, SF_DENS);
+        op_advect<1>(x, x0, b0, SF_U, SF_V, SF_W);
+    }
+
+    void set_iters(int iters) override {
+        SF_REQUIRE(iters >= 0, "iters must be >= 0");
+        K_ = iters;
+    }
+    void set_coefficients(double dt, double diff, double visc) override {
+        dt_ = (T)dt;
+        diff_ = (T)diff;
+        visc_ = (T)visc;
+    }
+
+    void sync() override {
+        SF_HIP(hipSetDevice(device_));
+        for (Slab& sl : slabs_) {
+            SF_HIP(hipStreamSynchronize(sl.cs));
+            SF_HIP(hipStreamSynchronize(sl.hs));
+        }
+        if (P_ > 1) {
+            for (Slab& sl : slabs_) {
+                int flag = 0;
+                SF_HIP(hipMemcpy(&flag, sl.d_flag, sizeof(int), hipMemcpyDeviceToHost));
+                if (flag) {
+                    SF_HIP(hipMemset(sl.d_flag, 0, sizeof(int)));
+                    throw Failure{SF_ERR_HALO_EXCEEDED,
+                                  "advect back-traced more than one plane across a slab boundary "
+                                  "(|dt*N*w| >= 1): results differ from the undecomposed solve"};
+                }
+            }
+        }
+    }
+
+    void timer_start() override {
+        SF_HIP(hipSetDevice(device_));
+        SF_HIP(hipEventRecord(t0_, slabs_[0].cs));
+    }
+    float timer_stop() override {
+        SF_HIP(hipEventRecord(t1_, slabs_[0].cs));
+        SF_HIP(hipEventSynchronize(t1_));
+        float ms = 0.f;
+        SF_HIP(hipEventElapsedTime(&ms, t0_, t1_));
+        return ms;
+    }
+
+    double copy_bandwidth(size_t bytes, int reps) override {
+        SF_HIP(hipSetDevice(device_));
+        bytes = (bytes + 4095) / 4096 * 4096;
+        if (copy_bytes_ != bytes) {
+            if (copy_src_) (void)hipFree(copy_src_);
+            if (copy_dst_) (void)hipFree(copy_dst_);
+            copy_src_ = copy_dst_ = nullptr;
+            SF_HIP(hipMalloc(&copy_src_, bytes));
+            SF_HIP(hipMalloc(&copy_dst_, bytes));
+            SF_HIP(hipMemset(copy_src_, 1, bytes));
+            SF_HIP(hipMemset(copy_dst_, 0, bytes));
+            copy_bytes_ = bytes;
+        }
+        const long n = (long)(bytes / 16);
+        hipStream_t st = slabs_[0].cs;
+        double best_ms = 1e30;
+        for (int r = 0; r <= reps; ++r) {
+            SF_HIP(hipEventRecord(t0_, st));
+            hipLaunchKernelGGL(sfk::copy16_kernel, dim3(stream_grid(n)), dim3(256), 0, st,
+                               (const float4*)copy_src_, (float4*)copy_dst_, n);
+            SF_HIP(hipEventRecord(t1_, st));
+            SF_HIP(hipEventSynchronize(t1_));
+            float ms = 0.f;
+            SF_HIP(hipEventElapsedTime(&ms, t0_, t1_));
+            if (r > 0 && ms < best_ms) best_ms = ms;
+        }
+        return 2.0 * (double)bytes / (best_ms * 1e-3) / 1e9;
+    }
+
+    void layout_info(int* pitch, int* planes, size_t* bytes) const override {
+        if (pitch) *pitch = px_;
+        if (planes) *planes = nplanes_;
+        if (bytes) *bytes = (size_t)field_elems_ * sizeof(T);
+    }
+
+private:
+    // ---- helpers --------------------------------------------------------------------------
+    static void check_field(int f) { SF_REQUIRE(f >= 0 && f < SF_NUM_FIELDS, "field id out of range"); }
+    static void check_b(int b) { SF_REQUIRE(b >= 0 && b <= 3, "boundary mode b must be 0..3"); }
+
+    T* alloc_field() {
+        T* p = nullptr;
+        SF_HIP(hipMalloc(&p, (size_t)field_elems_ * sizeof(T)));
+        SF_HIP(hipMemset(p, 0, (size_t)field_elems_ * sizeof(T)));
+        return p;
+    }
+    T* ensure(Slab& sl, int f) {
+        if (!sl.field[f]) {
+            // allocation is synchronous with respect to the device; fine for the lazily created user slots
+            sl.field[f] = alloc_field();
+        }
+        return sl.field[f];
+    }
+    void swap_slots(int a, int b) {
+        for (Slab& sl : slabs_) std::swap(sl.field[a], sl.field[b]);
+    }
+    T diffusion_a(T coeff) const {
+        const T Nf = (T)N_;
+        return ((dt_ * coeff) * Nf) * Nf;
+    }
+    unsigned stream_grid(long nvec) const {
+        long blocks = (nvec + 255) / 256;
+        const long cap = (long)num_cu_ * 8;
+        return (unsigned)std::max(1L, std::min(blocks, cap));
+    }
+
+    void copy_planes_out(Slab& sl, int field, int kb, int ke, T* dst) {
+        SF_HIP(hipSetDevice(device_));
+        T* dev = ensure(sl, field);
+        const size_t S = (size_t)N_ + 2;
+        const int klb = kb - sl.geom.kg0;
+        SF_REQUIRE(klb >= 0 && ke - sl.geom.kg0 <= nplanes_, "plane range outside slab");
+        SF_HIP(hipMemcpy2DAsync(dst, S * sizeof(T), dev + (size_t)klb * plane_ + (lead_ - 1),
+                                (size_t)px_ * sizeof(T), S * sizeof(T), S * (size_t)(ke - kb),
+                                hipMemcpyDeviceToHost, sl.cs));
+    }
+
+    // Launch geometry over (vector columns, rows, plane chunks).
+    struct Tile {
+        dim3 grid, block;
+        int kchunk;
+    };
+    Tile tile(int nplanes, bool march) const {
+        const int nvec = ceil_div(N_, W);
+        int tx = 1;
+        while (tx < nvec && tx < 64) tx <<= 1;
+        const int ty = 256 / tx;
+        Tile t;
+        t.block = dim3(tx, ty, 1);
+        const int gx = ceil_div(nvec, tx), gy = ceil_div(N_, ty);
+        int kchunk = 1;
+        if (march) {
+            if (kchunk_ > 0) {
+                kchunk = kchunk_;
+            } else {
+                // enough blocks to fill 256 CUs several times over, but columns as long as possible
+                const long target = (long)num_cu_ * 16;
+                long gz = std::max(1L, std::min((long)nplanes, target / std::max(1, gx * gy)));
+                kchunk = ceil_div(nplanes, (int)gz);
+            }
+            kchunk = std::max(1, std::min(kchunk, nplanes));
+        }
+        t.kchunk = kchunk;
+        t.grid = dim3(gx, gy, ceil_div(nplanes, kchunk));
+        return t;
+    }
+
+    // Runs `launch(slab, kb, ke)` over the interior planes of every slab. With P > 1 the two
+    // slab-boundary planes go first, their completion is recorded, and the rest follows so that the
+    // halo exchange issued by the caller overlaps the interior work.
+    template <class F>
+    void for_planes(F launch) {
+        if (P_ == 1) {
+            launch(slabs_[0], 1, nzl_ + 1);
+            SF_HIP(hipGetLastError());
+            return;
+        }
+        for (Slab& sl : slabs_) {
+            launch(sl, 1, 2);
+            if (nzl_ >= 2) launch(sl, nzl_, nzl_ + 1);
+            SF_HIP(hipEventRecord(sl.boundary_done, sl.cs));
+            if (nzl_ > 2) launch(sl, 2, nzl_);
+        }
+        SF_HIP(hipGetLastError());
+    }
+
+    // Halo exchange of NF fields: first / last interior plane -> neighbour's ghost plane.
+    // Must follow for_planes (uses boundary_done). Compute streams wait on the result.
+    template <int NF>
+    void exchange(const int (&fields)[NF]) {
+        if (P_ == 1) return;
+        const size_t bytes = (size_t)plane_ * sizeof(T);
+        for (int s = 0; s < L_; ++s) {
+            Slab& sl = slabs_[s];
+            SF_HIP(hipStreamWaitEvent(sl.hs, sl.boundary_done, 0));
+            const bool has_lo = sl.gid > 0, has_hi = sl.gid < P_ - 1;
+            const bool lo_local = has_lo && s > 0, hi_local = has_hi && s < L_ - 1;
+            if (lo_local) SF_HIP(hipStreamWaitEvent(sl.hs, slabs_[s - 1].boundary_done, 0));
+            if (hi_local) SF_HIP(hipStreamWaitEvent(sl.hs, slabs_[s + 1].boundary_done, 0));
+            // pull from neighbours that live in this process
+            for (int f = 0; f < NF; ++f) {
+                T* mine = sl.field[fields[f]];
+                if (lo_local)
+                    SF_HIP(hipMemcpyAsync(mine, slabs_[s - 1].field[fields[f]] + (size_t)nzl_ * plane_, bytes,
+                                          hipMemcpyDeviceToDevice, sl.hs));
+                if (hi_local)
+                    SF_HIP(hipMemcpyAsync(mine + (size_t)(nzl_ + 1) * plane_,
+                                          slabs_[s + 1].field[fields[f]] + (size_t)plane_, bytes,
+                                          hipMemcpyDeviceToDevice, sl.hs));
+            }
+            // neighbours in other processes: grouped send/recv over RCCL (xGMI point-to-point)
+            const bool lo_remote = has_lo && !lo_local, hi_remote = has_hi && !hi_local;
+            if (lo_remote || hi_remote) {
+                const ncclDataType_t dt = sizeof(T) == 4 ? ncclFloat : ncclDouble;
+                SF_NCCL(ncclGroupStart());
+                for (int f = 0; f < NF; ++f) {
+                    T* mine = sl.field[fields[f]];
+                    if (lo_remote) {
+                        SF_NCCL(ncclSend(mine + (size_t)plane_, (size_t)plane_, dt, rank_ - 1, comm_, sl.hs));
+                        SF_NCCL(ncclRecv(mine, (size_t)plane_, dt, rank_ - 1, comm_, sl.hs));
+                    }
+                    if (hi_remote) {
+                        SF_NCCL(ncclSend(mine + (size_t)nzl_ * plane_, (size_t)plane_, dt, rank_ + 1, comm_, sl.hs));
+                        SF_NCCL(ncclRecv(mine + (size_t)(nzl_ + 1) * plane_, (size_t)plane_, dt, rank_ + 1, comm_,
+                                         sl.hs));
+                    }
+                }
+                SF_NCCL(ncclGroupEnd());
+            }
+            SF_HIP(hipEventRecord(sl.halo_done, sl.hs));
+        }
+        // consumers: my own ghosts, and neighbours that pulled from my planes must be done before I
+        // overwrite them two sweeps later
+        for (int s = 0; s < L_; ++s) {
+            Slab& sl = slabs_[s];
+            SF_HIP(hipStreamWaitEvent(sl.cs, sl.halo_done, 0));
+            if (s > 0) SF_HIP(hipStreamWaitEvent(sl.cs, slabs_[s - 1].halo_done, 0));
+            if (s < L_ - 1) SF_HIP(hipStreamWaitEvent(sl.cs, slabs_[s + 1].halo_done, 0));
+        }
+    }
+
+    template <int NF>
+    void op_add_source(const int (&x)[NF], const int (&s)[NF]) {
+        const long nvec = field_elems_ / W;
+        for (Slab& sl : slabs_) {
+            sfk::AddSourceArgs<T, NF> A;
+            for (int f = 0; f < NF; ++f) {
+                A.x[f] = ensure(sl, x[f]);
+                A.s[f] = ensure(sl, s[f]);
+            }
+            A.dt = dt_;
+            A.nvec = nvec;
+            hipLaunchKernelGGL((sfk::add_source_kernel<T, NF>), dim3(stream_grid(nvec)), dim3(256), 0, sl.cs, A);
+        }
+        SF_HIP(hipGetLastError());
+        // ghosts of x and s were current, so the ghosts of the result are current: no exchange
+    }
+
+    // K Jacobi sweeps on NF fields at once; scratch buffers are swapped into the slots.
+    template <int NF>
+    void op_lin_solve(const int (&x)[NF], const int (&x0)[NF], const int (&b)[NF], T a, T c, int K) {
+        static_assert(NF <= NSCRATCH, "not enough scratch buffers");
+        const T inv = T(1) / c;
+        for (Slab& sl : slabs_)
+            for (int f = 0; f < NF; ++f) {
+                ensure(sl, x[f]);
+                ensure(sl, x0[f]);
+            }
+        for (int it = 0; it < K; ++it) {
+            for_planes([&](Slab& sl, int kb, int ke) {
+                sfk::JacobiArgs<T, NF> A;
+                for (int f = 0; f < NF; ++f) {
+                    A.x[f] = sl.field[x[f]];
+                    A.x0[f] = sl.field[x0[f]];
+                    A.xn[f] = sl.scratch[f];
+                    A.b[f] = b[f];
+                }
+                A.a = a;
+                A.inv = inv;
+                const Tile t = tile(ke - kb, true);
+                hipLaunchKernelGGL((sfk::jacobi_kernel<T, NF>), t.grid, t.block, 0, sl.cs, sl.geom, A, kb, ke,
+                                   t.kchunk);
+            });
+            // the new iterate becomes the field; the old buffer becomes scratch
+            for (Slab& sl : slabs_)
+                for (int f = 0; f < NF; ++f) std::swap(sl.field[x[f]], sl.scratch[f]);
+            exchange<NF>(x);
+        }
+    }
+
+    template <int NF>
+    void op_advect(const int (&d)[NF], const int (&d0)[NF], const int (&b)[NF], int u, int v, int w) {
+        const T dt0 = dt_ * (T)N_;
+        for (Slab& sl : slabs_) {
+            for (int f = 0; f < NF; ++f) {
+                ensure(sl, d[f]);
+                ensure(sl, d0[f]);
+            }
+            ensure(sl, u);
+            ensure(sl, v);
+            ensure(sl, w);
+        }
+        for_planes([&](Slab& sl, int kb, int ke) {
+            sfk::AdvectArgs<T, NF> A;
+            for (int f = 0; f < NF; ++f) {
+                A.d[f] = sl.field[d[f]];
+                A.d0[f] = sl.field[d0[f]];
+                A.b[f] = b[f];
+            }
+            A.u = sl.field[u];
+            A.v = sl.field[v];
+            A.w = sl.field[w];
+            A.dt0 = dt0;
+            A.flag = sl.d_flag;
+            const Tile t = tile(ke - kb, false);
+            hipLaunchKernelGGL((sfk::advect_kernel<T, NF>), t.grid, t.block, 0, sl.cs, sl.geom, A, kb, ke);
+        });
+        exchange<NF>(d);
+    }
+
+    void op_project(int u, int v, int w, int p, int div) {
+        const T Nf = (T)N_;
+        const T h = T(1) / Nf;
+        auto args = [&](Slab& sl) {
+            sfk::ProjectArgs<T> A;
+            A.u = ensure(sl, u);
+            A.v = ensure(sl, v);
+            A.w = ensure(sl, w);
+            A.p = ensure(sl, p);
+            A.div = ensure(sl, div);
+            A.c_div = T(-0.5) * h;
+            A.c_grad = T(0.5) * Nf;
+            return A;
+        };
+        for (Slab& sl : slabs_) {
+            ensure(sl, p);
+            SF_HIP(hipMemsetAsync(sl.field[p], 0, (size_t)field_elems_ * sizeof(T), sl.cs));
+        }
+        for_planes([&](Slab& sl, int kb, int ke) {
+            const Tile t = tile(ke - kb, false);
+            hipLaunchKernelGGL((sfk::project_div_kernel<T>), t.grid, t.block, 0, sl.cs, sl.geom, args(sl), kb, ke);
+        });
+        // no exchange here: lin_solve reads div only at cell centres, and p is zero, ghosts included
+        const int dv[1] = {div};
+        const int ps[1] = {p}, b0[1] = {0};
+        op_lin_solve<1>(ps, dv, b0, T(1), T(6), K_);
+        for_planes([&](Slab& sl, int kb, int ke) {
+            const Tile t = tile(ke - kb, false);
+            hipLaunchKernelGGL((sfk::project_sub_kernel<T>), t.grid, t.block, 0, sl.cs, sl.geom, args(sl), kb, ke);
+        });
+        const int uvw[3] = {u, v, w};
+        exchange<3>(uvw);
+    }
+
+    int N_, K_, device_;
+    int L_ = 1, nranks_ = 1, rank_ = 0, P_ = 1;
+    T dt_{}, diff_{}, visc_{};
+    int num_cu_ = 256;
+    int nzl_ = 0, lead_ = 0, px_ = 0, nplanes_ = 0, kchunk_ = 0;
+    long plane_ = 0, field_elems_ = 0;
+    std::vector<Slab> slabs_;
+    ncclComm_t comm_ = nullptr;
+    hipEvent_t t0_ = nullptr, t1_ = nullptr;
+    void* copy_src_ = nullptr;
+    void* copy_dst_ = nullptr;
+    size_t copy_bytes_ = 0;
+};
+
+}  // namespace
+
+struct sf_ctx {
+    std::unique_ptr<SolverBase> impl;
+    std::string err;
+};
+
+namespace {
+
+template <class F>
+int guarded(sf_ctx* ctx, F&& body) {
+    if (!ctx || !ctx->impl) return SF_ERR_INVALID;
+    try {
+        body(*ctx->impl);
+        return SF_OK;
+    } catch (const Failure& f) {
+        ctx->err = f.msg;
+        return f.code;
+    } catch (const std::exception& e) {
+        ctx->err = e.what();
+        return SF_ERR_INVALID;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* sf_version(void) { return "sfgpu 0.1 gfx950 hip"; }
+
+const char* sf_status_string(int status) {
+    switch (status) {
+        case SF_OK: return "SF_OK";
+        case SF_ERR_INVALID: return "SF_ERR_INVALID";
+        case SF_ERR_HIP: return "SF_ERR_HIP";
+        case SF_ERR_RCCL: return "SF_ERR_RCCL";
+        case SF_ERR_HALO_EXCEEDED: return "SF_ERR_HALO_EXCEEDED";
+        case SF_ERR_NO_DEVICE: return "SF_ERR_NO_DEVICE";
+        default: return "SF_ERR_UNKNOWN";
+    }
+}
+
+int sf_nccl_unique_id(void* out) {
+    if (!out) return SF_ERR_INVALID;
+    ncclUniqueId id;
+    if (ncclGetUniqueId(&id) != ncclSuccess) return SF_ERR_RCCL;
+    std::memset(out, 0, SF_NCCL_ID_BYTES);
+    std::memcpy(out, &id, sizeof id);
+    return SF_OK;
+}
+
+int sf_create(sf_ctx** out, const sf_params* p) {
+    if (!out) return SF_ERR_INVALID;
+    *out = nullptr;
+    if (!p) {
+        g_create_error = "null params";
+        return SF_ERR_INVALID;
+    }
+    try {
+        std::unique_ptr<sf_ctx> ctx(new sf_ctx);
+        if (p->dtype == SF_F32)
+            ctx->impl.reset(new Solver<float>(*p));
+        else if (p->dtype == SF_F64)
+            ctx->impl.reset(new Solver<double>(*p));
+        else
+            throw Failure{SF_ERR_INVALID, "dtype must be SF_F32 or SF_F64"};
+        *out = ctx.release();
+        return SF_OK;
+    } catch (const Failure& f) {
+        g_create_error = f.msg;
+        return f.code;
+    } catch (const std::exception& e) {
+        g_create_error = e.what();
+        return SF_ERR_INVALID;
+    }
+}
+
+void sf_destroy(sf_ctx* ctx) { delete ctx; }
+
+int sf_upload(sf_ctx* ctx, int field, const void* host) {
+    return guarded(ctx, [&](SolverBase& s) { s.upload(field, host); });
+}
+int sf_download(sf_ctx* ctx, int field, void* host) {
+    return guarded(ctx, [&](SolverBase& s) { s.download(field, host); });
+}
+int sf_download_planes(sf_ctx* ctx, int field, int k_begin, int k_end, void* host) {
+    return guarded(ctx, [&](SolverBase& s) { s.download_planes(field, k_begin, k_end, host); });
+}
+int sf_owned_planes(const sf_ctx* ctx, int* k_begin, int* k_end) {
+    if (!ctx || !ctx->impl) return SF_ERR_INVALID;
+    ctx->impl->owned_planes(k_begin, k_end);
+    return SF_OK;
+}
+int sf_fill(sf_ctx* ctx, int field, double value) {
+    return guarded(ctx, [&](SolverBase& s) { s.fill(field, value); });
+}
+int sf_copy_field(sf_ctx* ctx, int dst, int src) {
+    return guarded(ctx, [&](SolverBase& s) { s.copy_field(dst, src); });
+}
+int vel_step(sf_ctx* ctx) {
+    return guarded(ctx, [&](SolverBase& s) { s.vel_step(); });
+}
+int dens_step(sf_ctx* ctx) {
+    return guarded(ctx, [&](SolverBase& s) { s.dens_step(); });
+}
+int sf_add_source(sf_ctx* ctx, int x, int src) {
+    return guarded(ctx, [&](SolverBase& s) { s.add_source(x, src); });
+}
+int sf_set_bnd(sf_ctx* ctx, int b, int x) {
+    return guarded(ctx, [&](SolverBase& s) { s.set_bnd(b, x); });
+}
+int sf_lin_solve(sf_ctx* ctx, int b, int x, int x0, double a, double c, int iters) {
+    return guarded(ctx, [&](SolverBase& s) { s.lin_solve(b, x, x0, a, c, iters); });
+}
+int sf_diffuse(sf_ctx* ctx, int b, int x, int x0, double diff) {
+    return guarded(ctx, [&](SolverBase& s) { s.diffuse(b, x, x0, diff); });
+}
+int sf_advect(sf_ctx* ctx, int b, int d, int d0, int u, int v, int w) {
+    return guarded(ctx, [&](SolverBase& s) { s.advect(b, d, d0, u, v, w); });
+}
+int sf_project(sf_ctx* ctx, int u, int v, int w, int p, int div) {
+    return guarded(ctx, [&](SolverBase& s) { s.project(u, v, w, p, div); });
+}
+int sf_set_iters(sf_ctx* ctx, int iters) {
+    return guarded(ctx, [&](SolverBase& s) { s.set_iters(iters); });
+}
+int sf_set_coefficients(sf_ctx* ctx, double dt, double diff, double visc) {
+    return guarded(ctx, [&](SolverBase& s) { s.set_coefficients(dt, diff, visc); });
+}
+int sf_sync(sf_ctx* ctx) {
+    return guarded(ctx, [&](SolverBase& s) { s.sync(); });
+}
+const char* sf_last_error(const sf_ctx* ctx) {
+    if (!ctx) return g_create_error.c_str();
+    return ctx->err.c_str();
+}
+int sf_timer_start(sf_ctx* ctx) {
+    return guarded(ctx, [&](SolverBase& s) { s.timer_start(); });
+}
+int sf_timer_stop(sf_ctx* ctx, float* ms) {
+    return guarded(ctx, [&](SolverBase& s) {
+        const float t = s.timer_stop();
+        if (ms) *ms = t;
+    });
+}
+int sf_measure_copy_bandwidth(sf_ctx* ctx, size_t bytes, int reps, double* gbps) {
+    return guarded(ctx, [&](SolverBase& s) {
+        const double r = s.copy_bandwidth(bytes, reps);
+        if (gbps) *gbps = r;
+    });
+}
+int sf_layout_info(const sf_ctx* ctx, int* row_pitch, int* planes_per_slab, size_t* bytes_per_field) {
+    if (!ctx || !ctx->impl) return SF_ERR_INVALID;
+    ctx->impl->layout_info(row_pitch, planes_per_slab, bytes_per_field);
+    return SF_OK;
+}
+
+}  // extern "C"

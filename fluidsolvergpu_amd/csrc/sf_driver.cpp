@@ -1,0 +1,206 @@
+// sf_driver.cpp — C++ host driver over the C ABI (include/sfgpu.h) and the VTK frame writer.
+//
+// Keeps the SHAPE of the reference's host loop (solver.cu:171-216, solver-unidyn.cu:313-573):
+// per step print "t= <t>", bracket the device work with an event pair, print
+// "done.\nElapsed kernel time: <ms> ms", and every <every> steps copy the fields back and write
+// "anim_s<frame>.vtk" (naming of solver.cu:210 / solver-unidyn.cu:484). Errors follow the
+// reference's CUDA_CHECK_RETURN convention (FluidGPU.cuh:34-41): print and exit(1).
+// Unlike the reference (compile-time #defines, argv ignored — solver.cu:17-19,64) everything is a
+// run-time option, and the grid solver behind vel_step/dens_step is the stable-fluids path of
+// docs/SPEC.md, not the reference's SPH kernels.
+//
+//   sf_driver [--n 64] [--steps 20] [--iters 20] [--dtype f32|f64] [--every 10] [--out DIR]
+//             [--binary] [--device 0] [--slabs 1] [--plumbing] [--quiet]
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../../include/sf_visit_writer.h"
+#include "../../include/sfgpu.h"
+
+static sf_ctx* g_ctx = nullptr;
+
+#define SF_CHECK_RETURN(value)                                                                  \
+    {                                                                                           \
+        int _m_stat = (value);                                                                  \
+        if (_m_stat != SF_OK) {                                                                 \
+            fprintf(stderr, "Error %s (%s) at line %d in file %s\n", sf_status_string(_m_stat), \
+                    sf_last_error(g_ctx), __LINE__, __FILE__);                                  \
+            exit(1);                                                                            \
+        }                                                                                       \
+    }
+
+struct Options {
+    int n = 64, steps = 20, iters = 20, every = 10, device = 0, slabs = 1;
+    bool f64 = false, binary = false, plumbing = false, quiet = false;
+    std::string out = ".";
+};
+
+static Options parse(int argc, char** argv) {
+    Options o;
+    for (int a = 1; a < argc; ++a) {
+        const std::string s = argv[a];
+        auto next = [&]() -> const char* {
+            if (a + 1 >= argc) {
+                fprintf(stderr, "missing value after %s\n", s.c_str());
+                exit(2);
+            }
+            return argv[++a];
+        };
+        if (s == "--n") o.n = atoi(next());
+        else if (s == "--steps") o.steps = atoi(next());
+        else if (s == "--iters") o.iters = atoi(next());
+        else if (s == "--every") o.every = atoi(next());
+        else if (s == "--device") o.device = atoi(next());
+        else if (s == "--slabs") o.slabs = atoi(next());
+        else if (s == "--out") o.out = next();
+        else if (s == "--dtype") o.f64 = (std::string(next()) == "f64");
+        else if (s == "--binary") o.binary = true;
+        else if (s == "--plumbing") o.plumbing = true;
+        else if (s == "--quiet") o.quiet = true;
+        else {
+            fprintf(stderr, "unknown option %s\n", s.c_str());
+            exit(2);
+        }
+    }
+    return o;
+}
+
+// Analytic inputs of docs/SPEC.md §5, evaluated in double and rounded to T.
+template <class T>
+struct Inputs {
+    std::vector<T> u, v, w, dens, su, sv, sw, sd;
+};
+
+template <class T>
+static Inputs<T> make_inputs(int N, double dt, bool plumbing) {
+    const size_t S = (size_t)N + 2, n = S * S * S;
+    Inputs<T> in;
+    for (auto* f : {&in.u, &in.v, &in.w, &in.dens, &in.su, &in.sv, &in.sw, &in.sd}) f->assign(n, T(0));
+    const double PI2 = 6.283185307179586476925286766559;
+    const double A = 0.5 / (dt * N);
+    auto IX = [&](int i, int j, int k) { return (size_t)i + S * ((size_t)j + S * (size_t)k); };
+    if (!plumbing) {
+        for (int k = 1; k <= N; ++k)
+            for (int j = 1; j <= N; ++j)
+                for (int i = 1; i <= N; ++i) {
+                    const double X = (i - 0.5) / N, Y = (j - 0.5) / N, Z = (k - 0.5) / N;
+                    in.u[IX(i, j, k)] = (T)(A * std::sin(PI2 * X) * std::cos(PI2 * Y));
+                    in.v[IX(i, j, k)] = (T)(-A * std::cos(PI2 * X) * std::sin(PI2 * Y));
+                    in.dens[IX(i, j, k)] =
+                        (T)(0.5 + 0.5 * std::sin(PI2 * X) * std::sin(PI2 * Y) * std::sin(PI2 * Z));
+                }
+    }
+    const int c = N / 2 > 0 ? N / 2 : 1;
+    in.sd[IX(c, c, c)] = T(100);
+    in.sv[IX(c, c, c)] = plumbing ? T(5) : (T)A;
+    return in;
+}
+
+template <class T>
+static void write_frame(const Options& o, int frame, const std::vector<T>& dens, const std::vector<T>& u,
+                        const std::vector<T>& v, const std::vector<T>& w) {
+    const int N = o.n;
+    const size_t S = (size_t)N + 2;
+    std::vector<float> d((size_t)N * N * N), vel((size_t)3 * N * N * N);
+    size_t q = 0;
+    for (int k = 1; k <= N; ++k)
+        for (int j = 1; j <= N; ++j)
+            for (int i = 1; i <= N; ++i, ++q) {
+                const size_t s = (size_t)i + S * ((size_t)j + S * (size_t)k);
+                d[q] = (float)dens[s];
+                vel[3 * q + 0] = (float)u[s];
+                vel[3 * q + 1] = (float)v[s];
+                vel[3 * q + 2] = (float)w[s];
+            }
+    std::ostringstream oss;
+    oss << o.out << "/anim_s" << frame << ".vtk";
+    const std::string name = oss.str();
+    int dims[3] = {N + 1, N + 1, N + 1};  // point counts; cells = N^3 (visit_writer.cpp:901-905)
+    int vardim[2] = {1, 3}, centering[2] = {0, 0};
+    const char* names[2] = {"density", "velocity"};
+    float* vars[2] = {d.data(), vel.data()};
+    write_regular_mesh(name.c_str(), o.binary ? 1 : 0, dims, 2, vardim, centering, names, vars);
+}
+
+template <class T>
+static int run(const Options& o) {
+    const double dt = 0.1, diff = 1e-4, visc = 1e-4;
+    sf_params p;
+    std::memset(&p, 0, sizeof p);
+    p.N = o.n;
+    p.dtype = sizeof(T) == 4 ? SF_F32 : SF_F64;
+    p.iters = o.iters;
+    p.dt = dt;
+    p.diff = diff;
+    p.visc = visc;
+    p.device = o.device;
+    p.nslabs_local = o.slabs;
+    p.rank = 0;
+    p.nranks = 1;
+    int rc = sf_create(&g_ctx, &p);
+    if (rc != SF_OK) {
+        fprintf(stderr, "Error %s (%s) at line %d in file %s\n", sf_status_string(rc), sf_last_error(nullptr),
+                __LINE__, __FILE__);
+        exit(1);
+    }
+    std::cout << sf_version() << "  N=" << o.n << " K=" << o.iters << " dtype=" << (sizeof(T) == 4 ? "f32" : "f64")
+              << " slabs=" << o.slabs << "\n";
+
+    Inputs<T> in = make_inputs<T>(o.n, dt, o.plumbing);
+    SF_CHECK_RETURN(sf_upload(g_ctx, SF_U, in.u.data()));
+    SF_CHECK_RETURN(sf_upload(g_ctx, SF_V, in.v.data()));
+    SF_CHECK_RETURN(sf_upload(g_ctx, SF_W, in.w.data()));
+    SF_CHECK_RETURN(sf_upload(g_ctx, SF_DENS, in.dens.data()));
+    for (int f : {SF_U, SF_V, SF_W}) SF_CHECK_RETURN(sf_set_bnd(g_ctx, f + 1, f));
+    SF_CHECK_RETURN(sf_set_bnd(g_ctx, 0, SF_DENS));
+    // sources stay resident in HBM and are re-injected every step
+    SF_CHECK_RETURN(sf_upload(g_ctx, SF_USER0, in.su.data()));
+    SF_CHECK_RETURN(sf_upload(g_ctx, SF_USER1, in.sv.data()));
+    SF_CHECK_RETURN(sf_upload(g_ctx, SF_USER2, in.sw.data()));
+    SF_CHECK_RETURN(sf_upload(g_ctx, SF_USER3, in.sd.data()));
+
+    const size_t n = ((size_t)o.n + 2) * ((size_t)o.n + 2) * ((size_t)o.n + 2);
+    std::vector<T> hd(n), hu(n), hv(n), hw(n);
+    double total_ms = 0;
+    for (int t = 0; t < o.steps; t++) {
+        if (!o.quiet) std::cout << "t= " << t << "\n";
+        float elapsedTime = 0.f;
+        SF_CHECK_RETURN(sf_timer_start(g_ctx));
+        SF_CHECK_RETURN(sf_copy_field(g_ctx, SF_U0, SF_USER0));
+        SF_CHECK_RETURN(sf_copy_field(g_ctx, SF_V0, SF_USER1));
+        SF_CHECK_RETURN(sf_copy_field(g_ctx, SF_W0, SF_USER2));
+        SF_CHECK_RETURN(sf_copy_field(g_ctx, SF_DENS0, SF_USER3));
+        SF_CHECK_RETURN(vel_step(g_ctx));
+        SF_CHECK_RETURN(dens_step(g_ctx));
+        SF_CHECK_RETURN(sf_timer_stop(g_ctx, &elapsedTime));
+        SF_CHECK_RETURN(sf_sync(g_ctx));
+        total_ms += elapsedTime;
+        if (!o.quiet) std::cout << "done.\nElapsed kernel time: " << elapsedTime << " ms\n";
+
+        if (o.every > 0 && t % o.every == 0) {
+            SF_CHECK_RETURN(sf_download(g_ctx, SF_DENS, hd.data()));
+            SF_CHECK_RETURN(sf_download(g_ctx, SF_U, hu.data()));
+            SF_CHECK_RETURN(sf_download(g_ctx, SF_V, hv.data()));
+            SF_CHECK_RETURN(sf_download(g_ctx, SF_W, hw.data()));
+            write_frame<T>(o, t / o.every, hd, hu, hv, hw);
+        }
+    }
+    const double cells = (double)o.n * o.n * o.n;
+    if (o.steps > 0)
+        std::cout << "mean step " << total_ms / o.steps << " ms, " << cells * o.steps / (total_ms * 1e-3) / 1e6
+                  << " Mcells/s\n";
+    sf_destroy(g_ctx);
+    g_ctx = nullptr;
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    const Options o = parse(argc, argv);
+    return o.f64 ? run<double>(o) : run<float>(o);
+}

@@ -1,0 +1,474 @@
+// sf_kernels.hpp — gfx950 (MI355X / CDNA4) kernels of the stable-fluids hot path.
+//
+// Numerics: docs/SPEC.md, expression by expression (built with -ffp-contract=off; results are
+// bit-identical to oracle/stable_fluids_oracle.hpp). Nothing here is derived from the reference,
+// which has no grid kernels; the layout idea "one ghost plane of the slowest index"
+// is the reference's `buffer = GRIDSIZE*GRIDSIZE` (solver-unidyn.cu:187).
+//
+// Device layout of one field of one slab (element type T, W = 16/sizeof(T) lanes per vector):
+//   planes kl = 0 .. nzl+1   (kl = 0 and nzl+1 are ghost planes; global k = kg0 + kl)
+//   rows   j  = 0 .. N+1
+//   row pitch px (multiple of 128 B); cell i lives at row_base + lead + (i-1), with
+//   lead*sizeof(T) = 128 B, so interior cell i = 1 starts a 128-byte line in every row and a
+//   64-lane wave reading 16 B per lane touches exactly eight whole lines. The shell cell i = 0 sits
+//   at lead-1, the shell cell N+1 right after the interior. A plane is one contiguous
+//   px*(N+2)-element block — one halo message.
+//
+// All kernels are HBM-bandwidth bound 7-point stencils / streams: 16-byte coalesced row loads,
+// k-marching with the k-1/k/k+1 values of the centre column kept in registers, boundary shells
+// (set_bnd) fused into the producing kernel so no separate O(N^2) launch is needed per sweep.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace sfk {
+
+struct Geom {
+    int N;        // interior cells per axis
+    int nzl;      // interior planes held by this slab
+    int kg0;      // global k of local plane 0 (= first interior k - 1)
+    int px;       // row pitch, elements
+    int lead;     // element offset of cell i = 1 inside a row
+    long plane;   // plane stride, elements (= px * (N+2))
+    int wall_lo;  // local plane 0 is the physical shell k = 0
+    int wall_hi;  // local plane nzl+1 is the physical shell k = N+1
+};
+
+template <class T> struct VecT;
+template <> struct VecT<float> {
+    typedef float type __attribute__((ext_vector_type(4)));
+    static constexpr int W = 4;
+};
+template <> struct VecT<double> {
+    typedef double type __attribute__((ext_vector_type(2)));
+    static constexpr int W = 2;
+};
+
+template <class T>
+__device__ __forceinline__ typename VecT<T>::type ldv(const T* p) {
+    return *reinterpret_cast<const typename VecT<T>::type*>(p);
+}
+template <class T>
+__device__ __forceinline__ void stv(T* p, typename VecT<T>::type v) {
+    *reinterpret_cast<typename VecT<T>::type*>(p) = v;
+}
+
+// Offset of shell cell i = 0 of row (j, kl); cell i is at row0 + i.
+__device__ __forceinline__ long row0(const Geom& g, int j, int kl) {
+    return (long)kl * g.plane + (long)j * g.px + (g.lead - 1);
+}
+
+// Store the nv valid cells of a W-wide vector starting at cell i0 of the row whose i=0 is at `r`.
+template <class T, int W>
+__device__ __forceinline__ void store_cells(T* __restrict__ f, long r, int i0, const T (&v)[W], int nv) {
+    if (nv == W) {
+        typename VecT<T>::type o;
+#pragma unroll
+        for (int e = 0; e < W; ++e) o[e] = v[e];
+        stv(f + r + i0, o);
+    } else {
+#pragma unroll
+        for (int e = 0; e < W; ++e)
+            if (e < nv) f[r + i0 + e] = v[e];
+    }
+}
+
+// set_bnd fused into the producer (SPEC §3 set_bnd): the thread that produced interior cells
+// out[0..nv) at (i0.., j, kl) also writes every shell cell that depends only on them.
+template <class T, int W>
+__device__ __forceinline__ void emit_shells(T* __restrict__ f, const Geom& g, int b, int i0, int j,
+                                            int kl, const T (&out)[W], int nv) {
+    const int N = g.N;
+    const bool ilo = (i0 == 1), ihi = (i0 + nv - 1 == N);
+    const bool jlo = (j == 1), jhi = (j == N);
+    const int kg = g.kg0 + kl;
+    const bool klo = g.wall_lo && kg == 1, khi = g.wall_hi && kg == N;
+    if (!(ilo | ihi | jlo | jhi | klo | khi)) return;
+
+    const T sx = (b == 1) ? T(-1) : T(1);
+    const T sy = (b == 2) ? T(-1) : T(1);
+    const T sz = (b == 3) ? T(-1) : T(1);
+    const T half = T(0.5);
+    const T third = (T)(1.0 / 3.0);
+    const T vlo = out[0];
+    T vhi = out[0];
+#pragma unroll
+    for (int e = 1; e < W; ++e)
+        if (e == nv - 1) vhi = out[e];
+
+    const long r = row0(g, j, kl);
+    if (ilo) f[r] = sx * vlo;
+    if (ihi) f[r + N + 1] = sx * vhi;
+
+#pragma unroll
+    for (int sj = 0; sj < 2; ++sj) {
+        if (!(sj ? jhi : jlo)) continue;
+        const long rj = r + (sj ? (long)g.px : -(long)g.px);
+        T t[W];
+#pragma unroll
+        for (int e = 0; e < W; ++e) t[e] = sy * out[e];
+        store_cells<T, W>(f, rj, i0, t, nv);
+        if (ilo) f[rj] = half * (sy * vlo + sx * vlo);
+        if (ihi) f[rj + N + 1] = half * (sy * vhi + sx * vhi);
+    }
+#pragma unroll
+    for (int sk = 0; sk < 2; ++sk) {
+        if (!(sk ? khi : klo)) continue;
+        const long rk = r + (sk ? g.plane : -g.plane);
+        T t[W];
+#pragma unroll
+        for (int e = 0; e < W; ++e) t[e] = sz * out[e];
+        store_cells<T, W>(f, rk, i0, t, nv);
+        if (ilo) f[rk] = half * (sz * vlo + sx * vlo);
+        if (ihi) f[rk + N + 1] = half * (sz * vhi + sx * vhi);
+#pragma unroll
+        for (int sj = 0; sj < 2; ++sj) {
+            if (!(sj ? jhi : jlo)) continue;
+            const long rjk = rk + (sj ? (long)g.px : -(long)g.px);
+#pragma unroll
+            for (int e = 0; e < W; ++e) t[e] = half * (sz * out[e] + sy * out[e]);
+            store_cells<T, W>(f, rjk, i0, t, nv);
+#pragma unroll
+            for (int si = 0; si < 2; ++si) {
+                if (!(si ? ihi : ilo)) continue;
+                const T v = si ? vhi : vlo;
+                const T ex = half * (sz * v + sy * v);
+                const T ey = half * (sz * v + sx * v);
+                const T ez = half * (sy * v + sx * v);
+                f[rjk + (si ? N + 1 : 0)] = third * ((ex + ey) + ez);
+            }
+        }
+    }
+}
+
+// Thread -> (vector column, row). Returns false if the thread is outside the grid.
+template <int W>
+__device__ __forceinline__ bool thread_cell(const Geom& g, int& i0, int& j, int& nv) {
+    i0 = 1 + W * (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    j = 1 + (int)(blockIdx.y * blockDim.y + threadIdx.y);
+    if (i0 > g.N || j > g.N) return false;
+    nv = g.N - i0 + 1;
+    nv = nv > W ? W : nv;
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// add_source: x += dt*s over every stored element (SPEC: "all S^3 entries"; pads hold zeros).
+// Pure stream: 3 words per element.
+template <class T, int NF>
+struct AddSourceArgs {
+    T* x[NF];
+    const T* s[NF];
+    T dt;
+    long nvec;  // vectors per field
+};
+
+template <class T, int NF>
+__global__ void __launch_bounds__(256) add_source_kernel(AddSourceArgs<T, NF> A) {
+    constexpr int W = VecT<T>::W;
+    typedef typename VecT<T>::type V;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < A.nvec; q += stride) {
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+            V a = ldv(A.x[f] + q * W);
+            const V s = ldv(A.s[f] + q * W);
+#pragma unroll
+            for (int e = 0; e < W; ++e) a[e] = a[e] + A.dt * s[e];
+            stv(A.x[f] + q * W, a);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// lin_solve: one Jacobi sweep + fused set_bnd (SPEC §3 lin_solve). Algorithmic traffic 3 words
+// per cell (read x, read x0, write x'). Each thread owns a W-wide column piece and marches kchunk
+// planes keeping x[k-1], x[k], x[k+1] in registers; j±1 rows and the two i-neighbours come from
+// L1/L2 (they are lines this block or its neighbour has just loaded).
+template <class T, int NF>
+struct JacobiArgs {
+    const T* x[NF];
+    const T* x0[NF];
+    T* xn[NF];
+    int b[NF];
+    T a, inv;
+};
+
+template <class T, int NF>
+__global__ void __launch_bounds__(256) jacobi_kernel(Geom g, JacobiArgs<T, NF> A, int kb, int ke,
+                                                      int kchunk) {
+    constexpr int W = VecT<T>::W;
+    typedef typename VecT<T>::type V;
+    int i0, j, nv;
+    if (!thread_cell<W>(g, i0, j, nv)) return;
+    const int k0 = kb + (int)blockIdx.z * kchunk;
+    const int k1 = (k0 + kchunk < ke) ? k0 + kchunk : ke;
+    if (k0 >= k1) return;
+    const T a = A.a, inv = A.inv;
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+        const T* __restrict__ x = A.x[f];
+        const T* __restrict__ x0 = A.x0[f];
+        T* __restrict__ xn = A.xn[f];
+        long q = row0(g, j, k0) + i0;
+        V km = ldv(x + q - g.plane);
+        V c = ldv(x + q);
+        for (int kl = k0; kl < k1; ++kl, q += g.plane) {
+            const V kp = ldv(x + q + g.plane);
+            const V jm = ldv(x + q - g.px);
+            const V jp = ldv(x + q + g.px);
+            const V s = ldv(x0 + q);
+            const T xm = x[q - 1];
+            const T xp = x[q + W];
+            T out[W];
+#pragma unroll
+            for (int e = 0; e < W; ++e) {
+                const T left = (e == 0) ? xm : c[e - 1];
+                const T right = (e == W - 1) ? xp : c[e + 1];
+                out[e] = (s[e] + a * (((left + right) + (jm[e] + jp[e])) + (km[e] + kp[e]))) * inv;
+            }
+            store_cells<T, W>(xn, q - i0, i0, out, nv);
+            emit_shells<T, W>(xn, g, A.b[f], i0, j, kl, out, nv);
+            km = c;
+            c = kp;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// advect: semi-Lagrangian back-trace + trilinear interpolation + fused set_bnd (SPEC §3 advect).
+// NF fields share one back-trace (vel_step advects u,v,w through the same velocity).
+// Algorithmic traffic: 3 (velocity) + NF (gather, assuming reuse) + NF (write) words per cell.
+template <class T, int NF>
+struct AdvectArgs {
+    T* d[NF];
+    const T* d0[NF];
+    int b[NF];
+    const T* u;
+    const T* v;
+    const T* w;
+    T dt0;
+    int* flag;  // set to 1 if a back-trace left the planes this slab stores
+};
+
+template <class T, int NF>
+__global__ void __launch_bounds__(256) advect_kernel(Geom g, AdvectArgs<T, NF> A, int kb, int ke) {
+    constexpr int W = VecT<T>::W;
+    typedef typename VecT<T>::type V;
+    int i0, j, nv;
+    if (!thread_cell<W>(g, i0, j, nv)) return;
+    const int kl = kb + (int)blockIdx.z;
+    if (kl >= ke) return;
+    const int N = g.N;
+    const T Nf = (T)N;
+    const T lo = T(0.5), hi = Nf + T(0.5);
+    const long q = row0(g, j, kl) + i0;
+    const V uu = ldv(A.u + q), vv = ldv(A.v + q), ww = ldv(A.w + q);
+    const int kg = g.kg0 + kl;
+    T out[NF][W];
+    bool bad = false;
+#pragma unroll
+    for (int e = 0; e < W; ++e) {
+#pragma unroll
+        for (int f = 0; f < NF; ++f) out[f][e] = T(0);
+        if (e >= nv) continue;
+        T x = (T)(i0 + e) - A.dt0 * uu[e];
+        T y = (T)j - A.dt0 * vv[e];
+        T z = (T)kg - A.dt0 * ww[e];
+        if (x < lo) x = lo;
+        if (x > hi) x = hi;
+        if (y < lo) y = lo;
+        if (y > hi) y = hi;
+        if (z < lo) z = lo;
+        if (z > hi) z = hi;
+        int ia = (x == x) ? (int)x : 0;
+        int ja = (y == y) ? (int)y : 0;
+        int ka = (z == z) ? (int)z : 0;
+        ia = ia < 0 ? 0 : (ia > N ? N : ia);
+        ja = ja < 0 ? 0 : (ja > N ? N : ja);
+        ka = ka < 0 ? 0 : (ka > N ? N : ka);
+        const T s1 = x - (T)ia, s0 = T(1) - s1;
+        const T t1 = y - (T)ja, t0 = T(1) - t1;
+        const T r1 = z - (T)ka, r0 = T(1) - r1;
+        int kla = ka - g.kg0;  // local plane of k0; k1 = kla + 1 must also be stored
+        if (kla < 0 || kla > g.nzl) {
+            bad = true;
+            kla = kla < 0 ? 0 : g.nzl;
+        }
+        const long p00 = row0(g, ja, kla) + ia;  // (i0,j0,k0)
+        const long p01 = p00 + g.plane;          // (i0,j0,k1)
+        const long p10 = p00 + g.px;             // (i0,j1,k0)
+        const long p11 = p10 + g.plane;          // (i0,j1,k1)
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+            const T* __restrict__ d0 = A.d0[f];
+            out[f][e] = s0 * (t0 * (r0 * d0[p00] + r1 * d0[p01]) + t1 * (r0 * d0[p10] + r1 * d0[p11])) +
+                        s1 * (t0 * (r0 * d0[p00 + 1] + r1 * d0[p01 + 1]) +
+                              t1 * (r0 * d0[p10 + 1] + r1 * d0[p11 + 1]));
+        }
+    }
+    if (bad) atomicOr(A.flag, 1);
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+        store_cells<T, W>(A.d[f], q - i0, i0, out[f], nv);
+        emit_shells<T, W>(A.d[f], g, A.b[f], i0, j, kl, out[f], nv);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// project, first half: div = c_div*((du + dv) + dw), set_bnd(0, div). p is zeroed by the caller
+// (hipMemsetAsync over the whole field, which also covers set_bnd(0,p) and the ghost planes).
+template <class T>
+struct ProjectArgs {
+    T* u;
+    T* v;
+    T* w;
+    T* p;
+    T* div;
+    T c_div, c_grad;
+};
+
+template <class T>
+__global__ void __launch_bounds__(256) project_div_kernel(Geom g, ProjectArgs<T> A, int kb, int ke) {
+    constexpr int W = VecT<T>::W;
+    typedef typename VecT<T>::type V;
+    int i0, j, nv;
+    if (!thread_cell<W>(g, i0, j, nv)) return;
+    const int kl = kb + (int)blockIdx.z;
+    if (kl >= ke) return;
+    const long q = row0(g, j, kl) + i0;
+    const V uc = ldv(A.u + q);
+    const T um = A.u[q - 1], up = A.u[q + W];
+    const V vm = ldv(A.v + q - g.px), vp = ldv(A.v + q + g.px);
+    const V wm = ldv(A.w + q - g.plane), wp = ldv(A.w + q + g.plane);
+    T out[W];
+#pragma unroll
+    for (int e = 0; e < W; ++e) {
+        const T left = (e == 0) ? um : uc[e - 1];
+        const T right = (e == W - 1) ? up : uc[e + 1];
+        out[e] = A.c_div * (((right - left) + (vp[e] - vm[e])) + (wp[e] - wm[e]));
+    }
+    store_cells<T, W>(A.div, q - i0, i0, out, nv);
+    emit_shells<T, W>(A.div, g, 0, i0, j, kl, out, nv);
+}
+
+// project, second half: u -= c_grad*dp/di etc., set_bnd(1,u), (2,v), (3,w).
+template <class T>
+__global__ void __launch_bounds__(256) project_sub_kernel(Geom g, ProjectArgs<T> A, int kb, int ke) {
+    constexpr int W = VecT<T>::W;
+    typedef typename VecT<T>::type V;
+    int i0, j, nv;
+    if (!thread_cell<W>(g, i0, j, nv)) return;
+    const int kl = kb + (int)blockIdx.z;
+    if (kl >= ke) return;
+    const long q = row0(g, j, kl) + i0;
+    const T* __restrict__ p = A.p;
+    const V pc = ldv(p + q);
+    const T pm = p[q - 1], pp = p[q + W];
+    const V pjm = ldv(p + q - g.px), pjp = ldv(p + q + g.px);
+    const V pkm = ldv(p + q - g.plane), pkp = ldv(p + q + g.plane);
+    const V uc = ldv(A.u + q), vc = ldv(A.v + q), wc = ldv(A.w + q);
+    T ou[W], ov[W], ow[W];
+#pragma unroll
+    for (int e = 0; e < W; ++e) {
+        const T left = (e == 0) ? pm : pc[e - 1];
+        const T right = (e == W - 1) ? pp : pc[e + 1];
+        ou[e] = uc[e] - A.c_grad * (right - left);
+        ov[e] = vc[e] - A.c_grad * (pjp[e] - pjm[e]);
+        ow[e] = wc[e] - A.c_grad * (pkp[e] - pkm[e]);
+    }
+    store_cells<T, W>(A.u, q - i0, i0, ou, nv);
+    store_cells<T, W>(A.v, q - i0, i0, ov, nv);
+    store_cells<T, W>(A.w, q - i0, i0, ow, nv);
+    emit_shells<T, W>(A.u, g, 1, i0, j, kl, ou, nv);
+    emit_shells<T, W>(A.v, g, 2, i0, j, kl, ov, nv);
+    emit_shells<T, W>(A.w, g, 3, i0, j, kl, ow, nv);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stand-alone set_bnd (SPEC §3), three dependent passes reading memory exactly like the oracle.
+// Only used by sf_set_bnd(); the step kernels fuse it. pass 0 = faces, 1 = edges, 2 = corners.
+template <class T>
+__global__ void __launch_bounds__(256) set_bnd_kernel(Geom g, T* __restrict__ x, int b, int pass) {
+    const int N = g.N;
+    const T sx = (b == 1) ? T(-1) : T(1);
+    const T sy = (b == 2) ? T(-1) : T(1);
+    const T sz = (b == 3) ? T(-1) : T(1);
+    const T half = T(0.5);
+    const T third = (T)(1.0 / 3.0);
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int E = N + 1;
+    const int klo_l = 1 - g.kg0;      // local plane of global k = 1   (valid if wall_lo)
+    const int khi_l = N - g.kg0;      // local plane of global k = N   (valid if wall_hi)
+    auto at = [&](int i, int j, int kl) -> T& { return x[row0(g, j, kl) + i]; };
+    if (pass == 0) {
+        // i- and j-faces of every local interior plane, k-faces on wall slabs.
+        const long per = (long)N * g.nzl;  // (a, kl) pairs
+        if (t < per) {
+            const int a = 1 + (int)(t % N), kl = 1 + (int)(t / N);
+            at(0, a, kl) = sx * at(1, a, kl);
+            at(E, a, kl) = sx * at(N, a, kl);
+            at(a, 0, kl) = sy * at(a, 1, kl);
+            at(a, E, kl) = sy * at(a, N, kl);
+        }
+        const long nn = (long)N * N;
+        if (t < nn) {
+            const int i = 1 + (int)(t % N), j = 1 + (int)(t / N);
+            if (g.wall_lo) at(i, j, klo_l - 1) = sz * at(i, j, klo_l);
+            if (g.wall_hi) at(i, j, khi_l + 1) = sz * at(i, j, khi_l);
+        }
+    } else if (pass == 1) {
+        // z-directed edges on every local interior plane
+        if (t < g.nzl) {
+            const int kl = 1 + (int)t;
+            for (int a = 0; a < 2; ++a)
+                for (int c = 0; c < 2; ++c) {
+                    const int I = a ? E : 0, In = a ? N : 1, J = c ? E : 0, Jn = c ? N : 1;
+                    at(I, J, kl) = half * (at(In, J, kl) + at(I, Jn, kl));
+                }
+        }
+        // x- and y-directed edges on wall planes
+        if (t < N) {
+            const int s = 1 + (int)t;
+            for (int c = 0; c < 2; ++c) {
+                if (!(c ? g.wall_hi : g.wall_lo)) continue;
+                const int K = c ? khi_l + 1 : klo_l - 1, Kn = c ? khi_l : klo_l;
+                for (int a = 0; a < 2; ++a) {
+                    const int J = a ? E : 0, Jn = a ? N : 1;
+                    at(s, J, K) = half * (at(s, Jn, K) + at(s, J, Kn));
+                    const int I = J, In = Jn;
+                    at(I, s, K) = half * (at(In, s, K) + at(I, s, Kn));
+                }
+            }
+        }
+    } else {
+        if (t < 8) {
+            const int a = (int)t & 1, c = ((int)t >> 1) & 1, e = ((int)t >> 2) & 1;
+            if (e ? g.wall_hi : g.wall_lo) {
+                const int I = a ? E : 0, In = a ? N : 1, J = c ? E : 0, Jn = c ? N : 1;
+                const int K = e ? khi_l + 1 : klo_l - 1, Kn = e ? khi_l : klo_l;
+                at(I, J, K) = third * ((at(In, J, K) + at(I, Jn, K)) + at(I, J, Kn));
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Utility kernels.
+template <class T>
+__global__ void __launch_bounds__(256) fill_kernel(T* __restrict__ x, T value, long nvec) {
+    constexpr int W = VecT<T>::W;
+    typename VecT<T>::type v;
+#pragma unroll
+    for (int e = 0; e < W; ++e) v[e] = value;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < nvec; q += stride) stv(x + q * W, v);
+}
+
+// float4 copy used to quote the achievable HBM rate in the same run as the solver numbers.
+__global__ void __launch_bounds__(256) copy16_kernel(const float4* __restrict__ src,
+                                                     float4* __restrict__ dst, long n) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += stride) dst[q] = src[q];
+}
+
+}  // namespace sfk
