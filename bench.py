@@ -1,0 +1,268 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the MI355X stable-fluids hot path.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = re-inject the resident sources (4 device copies) + vel_step + dens_step over the whole
+grid (BASELINE.json metric: Mcells/s per vel_step+dens_step, 20 Jacobi iterations). At N = 1 the
+workload is BASELINE.json configs[1]: 256^3 fp32, K = 20. For N > 1 the grid is slab-decomposed along
+k, one slab per GPU, with RCCL halo exchange; the per-GPU cell count is kept at ~256^3 (weak scaling:
+N_g = 324 / 408 / 512 for 2 / 4 / 8 GPUs). Inputs are the analytic fields of docs/SPEC.md §5, resident
+in HBM before the timed region starts.
+
+Rank 0 prints ONE JSON line. Besides the contract fields it carries
+  roofline     : the Jacobi lin_solve sweep (dominant kernel) timed with HIP events on its own stream
+  cpu_baseline : the serial CPU oracle (oracle/, "port") on the same workload, bounded sample
+The oracle is only the baseline/checker here, never the thing measured as `value`.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured float4 copy)
+WEAK_GRID = {1: 256, 2: 324, 4: 408, 8: 512}  # N_g^3 / gpus ~= 256^3, N_g divisible by gpus and by 4
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=0, help="grid size override (default: 256 per GPU, weak scaling)")
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--roofline-n", type=int, default=512, help="also time the lin_solve sweep at this size")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    return ap.parse_args()
+
+
+def analytic_planes(N, kb, ke, dt, dtype):
+    """SPEC §5 fields for global planes [kb, ke): dict of (ke-kb, N+2, N+2) arrays. Shells are zero
+    here and set on the device by sf_set_bnd."""
+    S = N + 2
+    A = 0.5 / (dt * N)
+    i = np.arange(S, dtype=np.float64)
+    X = (i - 0.5) / N
+    inside = (i >= 1) & (i <= N)
+    sx, cx = np.sin(2 * np.pi * X) * inside, np.cos(2 * np.pi * X) * inside
+    k = np.arange(kb, ke, dtype=np.float64)
+    Z = (k - 0.5) / N
+    inz = ((k >= 1) & (k <= N)).astype(np.float64)
+    sz = np.sin(2 * np.pi * Z) * inz
+    u2 = A * np.outer(cx, sx)  # [j, i] = A sin(2piX) cos(2piY)
+    v2 = -A * np.outer(sx, cx)  # [j, i] = -A cos(2piX) sin(2piY)
+    out = {
+        "u": (inz[:, None, None] * u2[None]).astype(dtype),
+        "v": (inz[:, None, None] * v2[None]).astype(dtype),
+        "w": np.zeros((ke - kb, S, S), dtype),
+        "dens": ((0.5 * inz[:, None, None]) * np.outer(inside, inside)[None]
+                 + 0.5 * sz[:, None, None] * np.outer(sx, sx)[None]).astype(dtype),
+    }
+    c = max(N // 2, 1)
+    for name, val in (("su", 0.0), ("sv", A), ("sw", 0.0), ("sd", 100.0)):
+        a = np.zeros((ke - kb, S, S), dtype)
+        if val and kb <= c < ke:
+            a[c - kb, c, c] = val
+        out[name] = a
+    return out
+
+
+def words_per_cell_step(K):
+    return 56 + 18 * K  # dens_step 8+3K, vel_step 48+15K
+
+
+def time_lin_solve(S, N, dtype, K, reps, device):
+    """Average duration of ONE Jacobi sweep launch (jacobi_kernel, NF = 1) at size N, HIP events on
+    the context's compute stream. Returns (microseconds per launch, min over reps of the same)."""
+    with S.FluidSolver(N, dtype=dtype, iters=K, device=device) as fs:
+        rng = np.random.RandomState(1)
+        plane = rng.standard_normal((1, N + 2, N + 2)).astype(fs.np_dtype)
+        for k in range(0, N + 2):
+            fs.upload_planes("dens", k, plane * (1.0 + 0.001 * k))
+            fs.upload_planes("dens0", k, plane * (0.5 - 0.001 * k))
+        a, c = 0.3, 1 + 6 * 0.3
+        fs.lin_solve(0, "dens", "dens0", a, c, 2)  # warm-up
+        fs.sync()
+        per = []
+        for _ in range(reps):
+            fs.timer_start()
+            fs.lin_solve(0, "dens", "dens0", a, c, K)
+            per.append(fs.timer_stop() * 1e3 / K)
+        fs.sync()
+        return float(np.mean(per)), float(np.min(per))
+
+
+def cpu_baseline(N, K, dtype, steps, dt, diff, visc):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+
+    npdt = np.float32 if dtype == "f32" else np.float64
+    f = analytic_planes(N, 0, N + 2, dt, npdt)
+    fields = {"u": f["u"], "v": f["v"], "w": f["w"], "dens": f["dens"]}
+    for b, n in ((1, "u"), (2, "v"), (3, "w"), (0, "dens")):
+        O.set_bnd(b, fields[n])
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fields.update({"u0": f["su"].copy(), "v0": f["sv"].copy(), "w0": f["sw"].copy(), "dens0": f["sd"].copy()})
+        O.step(N, fields, npdt(dt), npdt(diff), npdt(visc), K)
+    el = time.perf_counter() - t0
+    return {"value": N ** 3 * steps / el / 1e6, "unit": "Mcells/s", "cores": 1, "kind": "port",
+            "sample": f"{steps} x (vel_step+dens_step) at {N}^3 {dtype} K={K}, serial C++ oracle "
+                      f"(g++ -O2 -ffp-contract=off), {el:.1f} s", "host_cores_visible": os.cpu_count()}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world == 1:
+        # not launched by torch.distributed.run: start it as a child (nothing has touched the GPU yet)
+        port = os.environ.get("MASTER_PORT", "29531")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        # torch first, so that its bundled HIP runtime / RCCL are the ones libsfgpu.so binds to
+        import torch
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    from fluidsolvergpu_amd import solver as S
+
+    K, dt, diff, visc = args.iters, 0.1, 1e-4, 1e-4
+    N = args.n if args.n > 0 else WEAK_GRID.get(world, 256 * world)
+    assert N % world == 0, f"grid {N} not divisible by {world} ranks"
+
+    nccl_id = None
+    if world > 1:
+        box = [S.nccl_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        nccl_id = box[0]
+    fs = S.FluidSolver(N, dtype=args.dtype, iters=K, dt=dt, diff=diff, visc=visc, device=local_rank, rank=rank,
+                       nranks=world, nccl_id=nccl_id)
+    kb, ke = fs.stored_planes()
+    f = analytic_planes(N, kb, ke, dt, fs.np_dtype)
+    for name, slot in (("u", "u"), ("v", "v"), ("w", "w"), ("dens", "dens"), ("su", "user0"), ("sv", "user1"),
+                       ("sw", "user2"), ("sd", "user3")):
+        fs.upload_planes(slot, kb, f[name])
+    for b, n in ((1, "u"), (2, "v"), (3, "w"), (0, "dens")):
+        fs.set_bnd(b, n)
+    fs.sync()
+    del f
+
+    def step():
+        fs.copy_field("u0", "user0")
+        fs.copy_field("v0", "user1")
+        fs.copy_field("w0", "user2")
+        fs.copy_field("dens0", "user3")
+        fs.vel_step()
+        fs.dens_step()
+
+    def barrier():
+        fs.sync()
+        if dist is not None:
+            dist.barrier()
+            if "torch" in sys.modules and sys.modules["torch"].cuda.is_initialized():
+                sys.modules["torch"].cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # state sanity: finite, and the halo guard did not fire (sync would have raised)
+    kb_o, ke_o = fs.owned_planes()
+    probe = fs.download_planes("dens", kb_o, min(kb_o + 2, ke_o))
+    assert np.isfinite(probe).all(), "non-finite density after the timed steps"
+
+    out = None
+    if rank == 0:
+        cells = float(N) ** 3
+        ms_per_step = elapsed / args.steps * 1e3
+        value = cells * args.steps / elapsed / 1e6
+        wsize = 4 if args.dtype == "f32" else 8
+        step_bytes = cells * words_per_cell_step(K) * wsize
+        copy_gbps = fs.copy_bandwidth_gbps(1 << 30, 5)
+        out = {
+            "metric": "Mcells/s per vel_step+dens_step",
+            "value": value,
+            "unit": "Mcells/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": args.dtype,
+            "data": "synthetic (analytic fields of docs/SPEC.md §5, resident in HBM)",
+            "config": {"workload": f"{N}^3 {args.dtype}, K={K} Jacobi iters per lin_solve, vel_step+dens_step "
+                                   f"with per-step source re-injection", "grid": N, "jacobi_iters": K,
+                       "slabs": world, "cells_per_gpu": cells / world,
+                       "parallelism": f"k-slab x{world}" + (" (RCCL halo exchange)" if world > 1 else "")},
+            "achieved_hbm_gbps_step": step_bytes / (elapsed / args.steps) / 1e9 / world,
+            "step_algorithmic_bytes_per_cell": words_per_cell_step(K) * wsize,
+            "hbm_copy_gbps_same_run": copy_gbps,
+        }
+    fs.close()
+
+    if rank == 0:
+        # ---- roofline leg: the Jacobi sweep, per launch, HIP events on the launch stream -------
+        n_local = N if world == 1 else WEAK_GRID[1]
+        wsize = 4 if args.dtype == "f32" else 8
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get(f"jacobi_nf1_{args.dtype}_{n_local}")
+        us, us_min = time_lin_solve(S, n_local, args.dtype, K, 5, local_rank)
+        alg = float(n_local) ** 3 * 3 * wsize
+        out["roofline"] = {"bound": "hbm", "kernel": "jacobi_kernel<T,1> (lin_solve sweep + fused set_bnd)",
+                           "achieved": alg / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                           "frac": alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, "traffic": traffic,
+                           "grid": n_local, "us_per_launch": us, "us_per_launch_min": us_min,
+                           "algorithmic_bytes_per_launch": alg,
+                           "note": "3 words/cell/iteration; 256^3 working set (~240 MB) sits largely in the "
+                                   "256 MiB Infinity Cache, see roofline_hbm for the out-of-cache size"}
+        if args.roofline_n and args.roofline_n != n_local:
+            n2 = args.roofline_n
+            us2, us2_min = time_lin_solve(S, n2, args.dtype, K, 3, local_rank)
+            alg2 = float(n2) ** 3 * 3 * wsize
+            t2 = json.load(open(tpath)).get(f"jacobi_nf1_{args.dtype}_{n2}") if os.path.exists(tpath) else None
+            out["roofline_hbm"] = {"bound": "hbm", "achieved": alg2 / (us2 * 1e-6) / 1e9, "peak": HBM_PEAK_GBPS,
+                                   "unit": "GB/s", "frac": alg2 / (us2 * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                                   "traffic": t2, "grid": n2, "us_per_launch": us2, "us_per_launch_min": us2_min,
+                                   "algorithmic_bytes_per_launch": alg2}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(N, K, args.dtype, args.cpu_steps, dt, diff, visc)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

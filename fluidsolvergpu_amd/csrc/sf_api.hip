@@ -70,6 +70,7 @@ public:
     virtual void upload(int field, const void* host) = 0;
     virtual void download(int field, void* host) = 0;
     virtual void download_planes(int field, int kb, int ke, void* host) = 0;
+    virtual void upload_planes(int field, int kb, int ke, const void* host) = 0;
     virtual void owned_planes(int* kb, int* ke) const = 0;
     virtual void fill(int field, double value) = 0;
     virtual void copy_field(int dst, int src) = 0;
@@ -162,6 +163,7 @@ public:
             for (int f = 0; f < NSCRATCH; ++f) sl.scratch[f] = alloc_field();
             SF_HIP(hipMalloc(&sl.d_flag, sizeof(int)));
             SF_HIP(hipMemset(sl.d_flag, 0, sizeof(int)));
+            SF_HIP(hipDeviceSynchronize());
         }
         SF_HIP(hipEventCreate(&t0_));
         SF_HIP(hipEventCreate(&t1_));
@@ -239,6 +241,27 @@ public:
             if (b >= e) continue;
             any = true;
             copy_planes_out(sl, field, b, e, static_cast<T*>(host) + (size_t)(b - kb) * S * S);
+        }
+        SF_REQUIRE(any, "plane range not stored by this context");
+        for (Slab& sl : slabs_) SF_HIP(hipStreamSynchronize(sl.cs));
+    }
+
+    void upload_planes(int field, int kb, int ke, const void* host) override {
+        check_field(field);
+        SF_REQUIRE(host != nullptr, "null host pointer");
+        SF_REQUIRE(kb < ke, "empty plane range");
+        SF_HIP(hipSetDevice(device_));
+        const size_t S = (size_t)N_ + 2;
+        bool any = false;
+        for (Slab& sl : slabs_) {
+            T* dev = ensure(sl, field);
+            const int b = std::max(kb, sl.geom.kg0), e = std::min(ke, sl.geom.kg0 + nplanes_);
+            if (b >= e) continue;
+            any = true;
+            const T* src = static_cast<const T*>(host) + (size_t)(b - kb) * S * S;
+            SF_HIP(hipMemcpy2DAsync(dev + (size_t)(b - sl.geom.kg0) * plane_ + (lead_ - 1), (size_t)px_ * sizeof(T),
+                                    src, S * sizeof(T), S * sizeof(T), S * (size_t)(e - b), hipMemcpyHostToDevice,
+                                    sl.cs));
         }
         SF_REQUIRE(any, "plane range not stored by this context");
         for (Slab& sl : slabs_) SF_HIP(hipStreamSynchronize(sl.cs));
@@ -396,16 +419,20 @@ public:
             SF_HIP(hipStreamSynchronize(sl.hs));
         }
         if (P_ > 1) {
+            bool exceeded = false;
             for (Slab& sl : slabs_) {
                 int flag = 0;
                 SF_HIP(hipMemcpy(&flag, sl.d_flag, sizeof(int), hipMemcpyDeviceToHost));
                 if (flag) {
+                    exceeded = true;
                     SF_HIP(hipMemset(sl.d_flag, 0, sizeof(int)));
-                    throw Failure{SF_ERR_HALO_EXCEEDED,
-                                  "advect back-traced more than one plane across a slab boundary "
-                                  "(|dt*N*w| >= 1): results differ from the undecomposed solve"};
+                    SF_HIP(hipDeviceSynchronize());
                 }
             }
+            if (exceeded)
+                throw Failure{SF_ERR_HALO_EXCEEDED,
+                              "advect back-traced more than one plane across a slab boundary "
+                              "(|dt*N*w| >= 1): results differ from the undecomposed solve"};
         }
     }
 
@@ -432,6 +459,7 @@ public:
             SF_HIP(hipMalloc(&copy_dst_, bytes));
             SF_HIP(hipMemset(copy_src_, 1, bytes));
             SF_HIP(hipMemset(copy_dst_, 0, bytes));
+            SF_HIP(hipDeviceSynchronize());
             copy_bytes_ = bytes;
         }
         const long n = (long)(bytes / 16);
@@ -465,6 +493,9 @@ private:
         T* p = nullptr;
         SF_HIP(hipMalloc(&p, (size_t)field_elems_ * sizeof(T)));
         SF_HIP(hipMemset(p, 0, (size_t)field_elems_ * sizeof(T)));
+        // hipMemset on device memory may return before the fill has run, and the context's streams are
+        // non-blocking (they do not order against the null stream): wait here.
+        SF_HIP(hipDeviceSynchronize());
         return p;
     }
     T* ensure(Slab& sl, int f) {
@@ -816,6 +847,9 @@ int sf_download(sf_ctx* ctx, int field, void* host) {
 }
 int sf_download_planes(sf_ctx* ctx, int field, int k_begin, int k_end, void* host) {
     return guarded(ctx, [&](SolverBase& s) { s.download_planes(field, k_begin, k_end, host); });
+}
+int sf_upload_planes(sf_ctx* ctx, int field, int k_begin, int k_end, const void* host) {
+    return guarded(ctx, [&](SolverBase& s) { s.upload_planes(field, k_begin, k_end, host); });
 }
 int sf_owned_planes(const sf_ctx* ctx, int* k_begin, int* k_end) {
     if (!ctx || !ctx->impl) return SF_ERR_INVALID;

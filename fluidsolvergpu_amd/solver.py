@@ -26,7 +26,7 @@ NCCL_ID_BYTES = 128
 # every symbol include/sfgpu.h declares (tests check that the library exports all of them)
 ABI_SYMBOLS = (
     "sf_version", "sf_status_string", "sf_nccl_unique_id", "sf_create", "sf_destroy", "sf_upload",
-    "sf_download", "sf_download_planes", "sf_owned_planes", "sf_fill", "sf_copy_field", "vel_step",
+    "sf_download", "sf_download_planes", "sf_upload_planes", "sf_owned_planes", "sf_fill", "sf_copy_field", "vel_step",
     "dens_step", "sf_add_source", "sf_set_bnd", "sf_lin_solve", "sf_diffuse", "sf_advect", "sf_project",
     "sf_set_iters", "sf_set_coefficients", "sf_sync", "sf_last_error", "sf_timer_start", "sf_timer_stop",
     "sf_measure_copy_bandwidth", "sf_layout_info",
@@ -52,6 +52,7 @@ lib.sf_destroy.restype = None
 lib.sf_upload.argtypes = [_ctx, C.c_int, C.c_void_p]
 lib.sf_download.argtypes = [_ctx, C.c_int, C.c_void_p]
 lib.sf_download_planes.argtypes = [_ctx, C.c_int, C.c_int, C.c_int, C.c_void_p]
+lib.sf_upload_planes.argtypes = [_ctx, C.c_int, C.c_int, C.c_int, C.c_void_p]
 lib.sf_owned_planes.argtypes = [_ctx, C.POINTER(C.c_int), C.POINTER(C.c_int)]
 lib.sf_fill.argtypes = [_ctx, C.c_int, C.c_double]
 lib.sf_copy_field.argtypes = [_ctx, C.c_int, C.c_int]
@@ -155,6 +156,18 @@ class FluidSolver:
         self._ck(lib.sf_download_planes(self._h, _fid(field), int(k_begin), int(k_end),
                                         out.ctypes.data_as(C.c_void_p)))
         return out
+
+    def upload_planes(self, field, k_begin, array):
+        a = np.ascontiguousarray(array, dtype=self.np_dtype)
+        if a.ndim != 3 or a.shape[1:] != (self.N + 2, self.N + 2):
+            raise ValueError(f"expected shape (nplanes,{self.N + 2},{self.N + 2}), got {a.shape}")
+        self._ck(lib.sf_upload_planes(self._h, _fid(field), int(k_begin), int(k_begin) + a.shape[0],
+                                      a.ctypes.data_as(C.c_void_p)))
+
+    def stored_planes(self):
+        """Global planes this context stores: its interior planes plus one ghost/shell plane each side."""
+        kb, ke = self.owned_planes()
+        return kb - 1, ke + 1
 
     def owned_planes(self):
         kb, ke = C.c_int(), C.c_int()

@@ -85,7 +85,10 @@ int sf_download(sf_ctx* ctx, int field, void* host);
 /* Same for a run of whole planes: global k in [k_begin, k_end) must lie inside this context's
  * stored range; host points at plane k_begin ((N+2)^2 elements per plane). */
 int sf_download_planes(sf_ctx* ctx, int field, int k_begin, int k_end, void* host);
-/* First / one-past-last global interior plane owned by this context (1-based k). */
+int sf_upload_planes(sf_ctx* ctx, int field, int k_begin, int k_end, const void* host);
+/* First / one-past-last global interior plane owned by this context (1-based k). sf_upload_planes
+ * accepts any [k_begin, k_end) and copies the planes of it that this context STORES (its interior
+ * planes and the ghost / shell plane either side), so a rank can upload just its own part. */
 int sf_owned_planes(const sf_ctx* ctx, int* k_begin, int* k_end);
 
 /* Device-side helpers, asynchronous. */

@@ -263,13 +263,16 @@ def test_large_properties(N):
         fs.sync()
         for n in ("u", "v", "w", "dens"):
             assert not fs.download(n).any()
-        # (2) uniform density, zero velocity: unchanged by dens_step
+        # (2) uniform density, zero velocity, zero diffusivity (a = 0: each sweep returns x0 exactly):
+        # unchanged by dens_step
+        fs.set_coefficients(DT, 0.0, 0.0)
         fs.fill("dens", 0.75)
         fs.fill("dens0", 0.0)
         fs.dens_step()
         fs.sync()
         d = fs.download("dens")
         assert np.all(d == np.float32(0.75))
+        fs.set_coefficients(DT, DIFF, VISC)
         # (3) Jacobi fixed point: x0 := c*x - a*sum(x_nb) makes x a fixed point up to rounding; instead
         # use linearity-free exact check: zero neighbours. x = 0, x0 = r  ->  one sweep gives r*inv exactly.
         r = rng.standard_normal((N + 2,) * 3).astype(dtype)
