@@ -133,6 +133,8 @@ def main():
         sys.exit(subprocess.call(cmd))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "SF_FORCE_DEVICE" in os.environ:  # rehearsal of the multi-rank path on a one-GPU box
+        local_rank = int(os.environ["SF_FORCE_DEVICE"])
     dist = None
     if world > 1:
         # torch first, so that its bundled HIP runtime / RCCL are the ones libsfgpu.so binds to

@@ -174,6 +174,10 @@ public:
             SF_NCCL(ncclCommInitRank(&comm_, nranks_, id, rank_));
         }
         kchunk_ = env_int("SF_KCHUNK", 0);
+        jacobi_mode_ = env_int("SF_JACOBI", 2);
+        nt_mode_ = env_int("SF_NT", 2);
+        ishell_skip_ = env_int("SF_ISHELL", 1) != 0;
+        tx_override_ = env_int("SF_TX", 0);
         SF_HIP(hipDeviceSynchronize());
     }
 
@@ -671,14 +675,59 @@ private:
                 }
                 A.a = a;
                 A.inv = inv;
-                const Tile t = tile(ke - kb, true);
-                hipLaunchKernelGGL((sfk::jacobi_kernel<T, NF>), t.grid, t.block, 0, sl.cs, sl.geom, A, kb, ke,
-                                   t.kchunk);
+                launch_jacobi<NF>(sl, A, kb, ke, it == 0, it == K - 1);
             });
             // the new iterate becomes the field; the old buffer becomes scratch
             for (Slab& sl : slabs_)
                 for (int f = 0; f < NF; ++f) std::swap(sl.field[x[f]], sl.scratch[f]);
             exchange<NF>(x);
+        }
+    }
+
+    // Jacobi sweep launcher. SF_JACOBI: 0 = k-marching kernel, 1 = flat, 2 = flat + XCD bands (default).
+    // SF_NT: 0 never / 1 always / 2 auto non-temporal stores. SF_ISHELL: 0 = always read+write the i-shell,
+    // 1 = recompute it in intermediate sweeps (default). SF_TX overrides the lanes per row tile.
+    template <int NF, int FLAGS>
+    void launch_flat(Slab& sl, const sfk::JacobiArgs<T, NF>& A, int kb, int ke) {
+        const int nvec = ceil_div(N_, W);
+        int tx = 1;
+        const int txmax = tx_override_ > 0 ? tx_override_ : 64;
+        while (tx < nvec && tx < txmax) tx <<= 1;
+        const int ty = 256 / tx;
+        sfk::TileMap m;
+        m.gx = ceil_div(nvec, tx);
+        m.gy = ceil_div(N_, ty);
+        m.nxcd = 8;
+        m.band = (jacobi_mode_ >= 2 && m.gy >= 16) ? ceil_div(m.gy, 8) : 0;
+        const long per_plane = m.band > 0 ? (long)m.nxcd * m.gx * m.band : (long)m.gx * m.gy;
+        const long nblocks = per_plane * (ke - kb) * NF;
+        hipLaunchKernelGGL((sfk::jacobi_flat_kernel<T, NF, FLAGS>), dim3((unsigned)nblocks), dim3(tx, ty), 0, sl.cs,
+                           sl.geom, A, kb, ke, m);
+    }
+
+    template <int NF>
+    void launch_jacobi(Slab& sl, const sfk::JacobiArgs<T, NF>& A, int kb, int ke, bool first, bool last) {
+        if (jacobi_mode_ == 0) {
+            const Tile t = tile(ke - kb, true);
+            hipLaunchKernelGGL((sfk::jacobi_kernel<T, NF>), t.grid, t.block, 0, sl.cs, sl.geom, A, kb, ke, t.kchunk);
+            return;
+        }
+        // non-temporal stores pay once x, x0 and x' of all NF fields no longer fit the 256 MiB Infinity Cache
+        const bool nt = nt_mode_ == 1 ||
+                        (nt_mode_ == 2 && (size_t)field_elems_ * sizeof(T) * 3 * NF > ((size_t)384 << 20));
+        const bool ishell_mem = !ishell_skip_ || first;
+        const bool ishell_write = !ishell_skip_ || last;
+        using namespace sfk;
+        const int flags = (nt ? JF_NT_STORE : 0) | (ishell_mem ? JF_ISHELL_MEM : 0) | (ishell_write ? JF_ISHELL_WRITE : 0);
+        switch (flags) {
+            case 0: launch_flat<NF, 0>(sl, A, kb, ke); break;
+            case 1: launch_flat<NF, 1>(sl, A, kb, ke); break;
+            case 2: launch_flat<NF, 2>(sl, A, kb, ke); break;
+            case 3: launch_flat<NF, 3>(sl, A, kb, ke); break;
+            case 4: launch_flat<NF, 4>(sl, A, kb, ke); break;
+            case 5: launch_flat<NF, 5>(sl, A, kb, ke); break;
+            case 6: launch_flat<NF, 6>(sl, A, kb, ke); break;
+            default: launch_flat<NF, 7>(sl, A, kb, ke); break;
         }
     }
 
@@ -750,7 +799,8 @@ private:
     int L_ = 1, nranks_ = 1, rank_ = 0, P_ = 1;
     T dt_{}, diff_{}, visc_{};
     int num_cu_ = 256;
-    int nzl_ = 0, lead_ = 0, px_ = 0, nplanes_ = 0, kchunk_ = 0;
+    int nzl_ = 0, lead_ = 0, px_ = 0, nplanes_ = 0, kchunk_ = 0, jacobi_mode_ = 2, tx_override_ = 0, nt_mode_ = 2;
+    bool ishell_skip_ = true;
     long plane_ = 0, field_elems_ = 0;
     std::vector<Slab> slabs_;
     ncclComm_t comm_ = nullptr;

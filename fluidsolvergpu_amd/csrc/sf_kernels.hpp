@@ -76,9 +76,11 @@ __device__ __forceinline__ void store_cells(T* __restrict__ f, long r, int i0, c
 // out[0..nv) at (i0.., j, kl) also writes every shell cell that depends only on them.
 template <class T, int W>
 __device__ __forceinline__ void emit_shells(T* __restrict__ f, const Geom& g, int b, int i0, int j,
-                                            int kl, const T (&out)[W], int nv) {
+                                            int kl, const T (&out)[W], int nv, bool with_i = true) {
+    // with_i == false: leave every shell cell with i = 0 or i = N+1 unwritten (intermediate Jacobi
+    // sweeps recompute those on the fly instead of spending a whole extra line per row on them)
     const int N = g.N;
-    const bool ilo = (i0 == 1), ihi = (i0 + nv - 1 == N);
+    const bool ilo = with_i && (i0 == 1), ihi = with_i && (i0 + nv - 1 == N);
     const bool jlo = (j == 1), jhi = (j == N);
     const int kg = g.kg0 + kl;
     const bool klo = g.wall_lo && kg == 1, khi = g.wall_hi && kg == N;
@@ -232,6 +234,121 @@ __global__ void __launch_bounds__(256) jacobi_kernel(Geom g, JacobiArgs<T, NF> A
             c = kp;
         }
     }
+}
+
+// Flat (non-marching) variant: one thread per W cells of one plane, 1-D grid in memory order so the
+// set of lines in flight is a compact moving window (what a plain copy needs to reach ~6.2 TB/s on
+// this part). XCD banding: workgroups are dealt round-robin over the 8 XCDs (b % 8 labels the
+// XCD group), so the j-tiles are cut into 8 contiguous bands and group e only ever works on band
+// e — its j+-1 and k+-1 neighbour lines were fetched by the same XCD and hit in its own 4 MiB L2
+// instead of crossing the fabric. Placement affects speed only, never results.
+struct TileMap {
+    int gx;    // tiles along i
+    int gy;    // tiles along j
+    int band;  // j-tiles per XCD band (0: plain order)
+    int nxcd;  // 8 when banded
+};
+
+// Sweep flags.
+enum : int {
+    JF_NT_STORE = 1,     // non-temporal stores of x' (working set >> Infinity Cache)
+    JF_ISHELL_MEM = 2,   // read x[0], x[N+1] from memory (first sweep: x is caller data); otherwise they
+                         // are recomputed as sx*x[1], sx*x[N], which is what the previous sweep's fused
+                         // set_bnd stored (or would have stored)
+    JF_ISHELL_WRITE = 4  // write the i = 0 / N+1 shell cells of x' (last sweep, or P > 1 debug)
+};
+
+template <class T, int NF, int FLAGS>
+__global__ void __launch_bounds__(256) jacobi_flat_kernel(Geom g, JacobiArgs<T, NF> A, int kb, int ke,
+                                                           TileMap m) {
+    constexpr int W = VecT<T>::W;
+    typedef typename VecT<T>::type V;
+    constexpr bool NT = (FLAGS & JF_NT_STORE) != 0;
+    constexpr bool ISHELL_MEM = (FLAGS & JF_ISHELL_MEM) != 0;
+    constexpr bool ISHELL_WRITE = (FLAGS & JF_ISHELL_WRITE) != 0;
+    int it, jt, kk, f;
+    {
+        int r = (int)blockIdx.x;
+        if (m.band > 0) {
+            const int xcd = r % m.nxcd;
+            r /= m.nxcd;
+            it = r % m.gx;
+            r /= m.gx;
+            jt = xcd * m.band + r % m.band;
+            r /= m.band;
+        } else {
+            it = r % m.gx;
+            r /= m.gx;
+            jt = r % m.gy;
+            r /= m.gy;
+        }
+        const int nk = ke - kb;
+        kk = r % nk;
+        f = r / nk;  // field index: the slowest grid dimension (uniform per workgroup)
+        if (jt >= m.gy) return;
+    }
+    const int kl = kb + kk;
+    const int i0 = 1 + W * (it * (int)blockDim.x + (int)threadIdx.x);
+    const int j = 1 + jt * (int)blockDim.y + (int)threadIdx.y;
+    if (i0 > g.N || j > g.N) return;
+    int nv = g.N - i0 + 1;
+    nv = nv > W ? W : nv;
+    const T a = A.a, inv = A.inv;
+    const long q = row0(g, j, kl) + i0;
+    const T* __restrict__ x = A.x[0];
+    const T* __restrict__ x0 = A.x0[0];
+    T* __restrict__ xn = A.xn[0];
+    int b = A.b[0];
+#pragma unroll
+    for (int ff = 1; ff < NF; ++ff)
+        if (f == ff) {
+            x = A.x[ff];
+            x0 = A.x0[ff];
+            xn = A.xn[ff];
+            b = A.b[ff];
+        }
+    V c = ldv(x + q);
+    const V km = ldv(x + q - g.plane);
+    const V kp = ldv(x + q + g.plane);
+    const V jm = ldv(x + q - g.px);
+    const V jp = ldv(x + q + g.px);
+    const V s = NT ? __builtin_nontemporal_load(reinterpret_cast<const V*>(x0 + q)) : ldv(x0 + q);
+    T xm, xp;
+    if (ISHELL_MEM) {
+        xm = x[q - 1];
+        xp = x[q + W];
+    } else {
+        const T sx = (b == 1) ? T(-1) : T(1);
+        // interior neighbours come from the adjacent vectors; the two shell cells are recomputed
+        xm = (i0 == 1) ? sx * c[0] : x[q - 1];
+        T last = c[0];
+#pragma unroll
+        for (int e = 1; e < W; ++e)
+            if (e == nv - 1) last = c[e];
+        xp = (i0 + W - 1 < g.N) ? x[q + W] : sx * last;
+        if (nv < W) {
+            // the shell cell N+1 lies inside this vector: patch it so element nv-1 sees it
+#pragma unroll
+            for (int e = 1; e < W; ++e)
+                if (e == nv) c[e] = sx * last;
+        }
+    }
+    T out[W];
+#pragma unroll
+    for (int e = 0; e < W; ++e) {
+        const T left = (e == 0) ? xm : c[e - 1];
+        const T right = (e == W - 1) ? xp : c[e + 1];
+        out[e] = (s[e] + a * (((left + right) + (jm[e] + jp[e])) + (km[e] + kp[e]))) * inv;
+    }
+    if (NT && nv == W) {
+        V o;
+#pragma unroll
+        for (int e = 0; e < W; ++e) o[e] = out[e];
+        __builtin_nontemporal_store(o, reinterpret_cast<V*>(xn + q));
+    } else {
+        store_cells<T, W>(xn, q - i0, i0, out, nv);
+    }
+    emit_shells<T, W>(xn, g, b, i0, j, kl, out, nv, ISHELL_WRITE);
 }
 
 // ---------------------------------------------------------------------------------------------
