@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=0, help="grid size override (default: 256 per GPU, weak scaling)")
+    ap.add_argument("--grid", dest="n", type=int, default=0, help="grid size override (default: 256 per GPU, weak scaling)")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--roofline-n", type=int, default=512, help="also time the lin_solve sweep at this size")
@@ -131,29 +131,20 @@ def main():
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
                "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.call(cmd))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch  # noqa: F401  torch first: its bundled HIP runtime / RCCL are then the ones libsfgpu.so binds to
+    from fluidsolvergpu_amd import dist as sfdist
+
+    rank, local_rank, _ = sfdist.env_world()
     if "SF_FORCE_DEVICE" in os.environ:  # rehearsal of the multi-rank path on a one-GPU box
         local_rank = int(os.environ["SF_FORCE_DEVICE"])
-    dist = None
-    if world > 1:
-        # torch first, so that its bundled HIP runtime / RCCL are the ones libsfgpu.so binds to
-        import torch
-        import torch.distributed as dist
-
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist = sfdist.init("gloo")  # control plane only; the halo exchange is RCCL inside libsfgpu.so
     from fluidsolvergpu_amd import solver as S
 
     K, dt, diff, visc = args.iters, 0.1, 1e-4, 1e-4
     N = args.n if args.n > 0 else WEAK_GRID.get(world, 256 * world)
     assert N % world == 0, f"grid {N} not divisible by {world} ranks"
-
-    nccl_id = None
-    if world > 1:
-        box = [S.nccl_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(box, src=0)
-        nccl_id = box[0]
+    nccl_id = sfdist.share_nccl_id(dist, S.nccl_unique_id)
     fs = S.FluidSolver(N, dtype=args.dtype, iters=K, dt=dt, diff=diff, visc=visc, device=local_rank, rank=rank,
                        nranks=world, nccl_id=nccl_id)
     kb, ke = fs.stored_planes()
@@ -188,13 +179,7 @@ def main():
     for _ in range(args.steps):
         step()
     barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = sfdist.max_over_ranks(dist, time.perf_counter() - t0)
 
     # state sanity: finite, and the halo guard did not fire (sync would have raised)
     kb_o, ke_o = fs.owned_planes()

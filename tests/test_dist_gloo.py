@@ -1,0 +1,45 @@
+"""N > 1 host path on CPU: world_size 2 (and 4) over gloo, launched exactly like bench.py is
+(`python -m torch.distributed.run`, rendezvous on 127.0.0.1)."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("world,N,K,dtype", [(2, 8, 3, "f32"), (2, 6, 2, "f64"), (4, 8, 2, "f32")])
+def test_slab_schedule_over_gloo(tmp_path, world, N, K, dtype):
+    out = tmp_path / "result.txt"
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+           os.path.join(HERE, "dist_worker.py"), str(out), str(N), str(K), dtype]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert out.read_text() == "OK"
+
+
+def test_partition_arithmetic():
+    from fluidsolvergpu_amd import dist as d
+
+    N, P = 512, 8
+    seen = []
+    for r in range(P):
+        kb, ke = d.slab_planes(N, r, P)
+        seen += list(range(kb, ke))
+        ob, oe = d.output_planes(N, r, P)
+        assert (ob == 0) == (r == 0) and (oe == N + 2) == (r == P - 1)
+    assert seen == list(range(1, N + 1))
+    with pytest.raises(ValueError):
+        d.slab_planes(10, 0, 3)
