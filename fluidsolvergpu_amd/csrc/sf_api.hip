@@ -177,6 +177,7 @@ public:
         jacobi_mode_ = env_int("SF_JACOBI", 2);
         nt_mode_ = env_int("SF_NT", 2);
         ishell_skip_ = env_int("SF_ISHELL", 1) != 0;
+        rb_shape_ = env_int("SF_RB", 0);
         tx_override_ = env_int("SF_TX", 0);
         SF_HIP(hipDeviceSynchronize());
     }
@@ -684,11 +685,12 @@ private:
         }
     }
 
-    // Jacobi sweep launcher. SF_JACOBI: 0 = k-marching kernel, 1 = flat, 2 = flat + XCD bands (default).
-    // SF_NT: 0 never / 1 always / 2 auto non-temporal stores. SF_ISHELL: 0 = always read+write the i-shell,
-    // 1 = recompute it in intermediate sweeps (default). SF_TX overrides the lanes per row tile.
-    template <int NF, int FLAGS>
-    void launch_flat(Slab& sl, const sfk::JacobiArgs<T, NF>& A, int kb, int ke) {
+    // Jacobi sweep launcher. SF_JACOBI: 0 = k-marching kernel, 1 = register-blocked flat kernel, plain order,
+    // 2 = the same with XCD bands (default). SF_NT: 0 never / 1 always / 2 auto non-temporal stores.
+    // SF_ISHELL: 0 = always read+write the i-shell, 1 = recompute it in intermediate sweeps (default).
+    // SF_RB = "RJxRK" register block (11, 21, 22, 41, 14, 42, 24); SF_TX overrides the lanes per row tile.
+    template <int NF, bool NT, int RJ, int RK>
+    void launch_rb(Slab& sl, const sfk::JacobiArgs<T, NF>& A, int kb, int ke, bool first, bool last) {
         const int nvec = ceil_div(N_, W);
         int tx = 1;
         const int txmax = tx_override_ > 0 ? tx_override_ : 64;
@@ -696,13 +698,32 @@ private:
         const int ty = 256 / tx;
         sfk::TileMap m;
         m.gx = ceil_div(nvec, tx);
-        m.gy = ceil_div(N_, ty);
+        m.gy = ceil_div(N_, ty * RJ);
         m.nxcd = 8;
         m.band = (jacobi_mode_ >= 2 && m.gy >= 16) ? ceil_div(m.gy, 8) : 0;
+        m.ishell_mem = (!ishell_skip_ || first) ? 1 : 0;
+        m.ishell_write = (!ishell_skip_ || last) ? 1 : 0;
         const long per_plane = m.band > 0 ? (long)m.nxcd * m.gx * m.band : (long)m.gx * m.gy;
-        const long nblocks = per_plane * (ke - kb) * NF;
-        hipLaunchKernelGGL((sfk::jacobi_flat_kernel<T, NF, FLAGS>), dim3((unsigned)nblocks), dim3(tx, ty), 0, sl.cs,
-                           sl.geom, A, kb, ke, m);
+        const long nblocks = per_plane * ceil_div(ke - kb, RK) * NF;
+        hipLaunchKernelGGL((sfk::jacobi_rb_kernel<T, NF, NT, RJ, RK>), dim3((unsigned)nblocks), dim3(tx, ty), 0,
+                           sl.cs, sl.geom, A, kb, ke, m);
+    }
+
+    template <int NF, bool NT>
+    void launch_rb_shape(Slab& sl, const sfk::JacobiArgs<T, NF>& A, int kb, int ke, bool first, bool last) {
+        // measured (512^3 / 256^3 fp32): 2x2 blocks win once the sweep streams from HBM (286 vs 309 us),
+        // 1x1 wins while x, x0, x' sit in the Infinity Cache (30.8 vs 34.0 us)
+        const int shape = rb_shape_ > 0 ? rb_shape_ : (NT ? 22 : 11);
+        switch (shape) {
+            case 11: launch_rb<NF, NT, 1, 1>(sl, A, kb, ke, first, last); break;
+            case 21: launch_rb<NF, NT, 2, 1>(sl, A, kb, ke, first, last); break;
+            case 41: launch_rb<NF, NT, 4, 1>(sl, A, kb, ke, first, last); break;
+            case 12: launch_rb<NF, NT, 1, 2>(sl, A, kb, ke, first, last); break;
+            case 14: launch_rb<NF, NT, 1, 4>(sl, A, kb, ke, first, last); break;
+            case 42: launch_rb<NF, NT, 4, 2>(sl, A, kb, ke, first, last); break;
+            case 24: launch_rb<NF, NT, 2, 4>(sl, A, kb, ke, first, last); break;
+            default: launch_rb<NF, NT, 2, 2>(sl, A, kb, ke, first, last); break;
+        }
     }
 
     template <int NF>
@@ -715,20 +736,10 @@ private:
         // non-temporal stores pay once x, x0 and x' of all NF fields no longer fit the 256 MiB Infinity Cache
         const bool nt = nt_mode_ == 1 ||
                         (nt_mode_ == 2 && (size_t)field_elems_ * sizeof(T) * 3 * NF > ((size_t)384 << 20));
-        const bool ishell_mem = !ishell_skip_ || first;
-        const bool ishell_write = !ishell_skip_ || last;
-        using namespace sfk;
-        const int flags = (nt ? JF_NT_STORE : 0) | (ishell_mem ? JF_ISHELL_MEM : 0) | (ishell_write ? JF_ISHELL_WRITE : 0);
-        switch (flags) {
-            case 0: launch_flat<NF, 0>(sl, A, kb, ke); break;
-            case 1: launch_flat<NF, 1>(sl, A, kb, ke); break;
-            case 2: launch_flat<NF, 2>(sl, A, kb, ke); break;
-            case 3: launch_flat<NF, 3>(sl, A, kb, ke); break;
-            case 4: launch_flat<NF, 4>(sl, A, kb, ke); break;
-            case 5: launch_flat<NF, 5>(sl, A, kb, ke); break;
-            case 6: launch_flat<NF, 6>(sl, A, kb, ke); break;
-            default: launch_flat<NF, 7>(sl, A, kb, ke); break;
-        }
+        if (nt)
+            launch_rb_shape<NF, true>(sl, A, kb, ke, first, last);
+        else
+            launch_rb_shape<NF, false>(sl, A, kb, ke, first, last);
     }
 
     template <int NF>
@@ -799,7 +810,7 @@ private:
     int L_ = 1, nranks_ = 1, rank_ = 0, P_ = 1;
     T dt_{}, diff_{}, visc_{};
     int num_cu_ = 256;
-    int nzl_ = 0, lead_ = 0, px_ = 0, nplanes_ = 0, kchunk_ = 0, jacobi_mode_ = 2, tx_override_ = 0, nt_mode_ = 2;
+    int nzl_ = 0, lead_ = 0, px_ = 0, nplanes_ = 0, kchunk_ = 0, jacobi_mode_ = 2, tx_override_ = 0, nt_mode_ = 2, rb_shape_ = 0;
     bool ishell_skip_ = true;
     long plane_ = 0, field_elems_ = 0;
     std::vector<Slab> slabs_;

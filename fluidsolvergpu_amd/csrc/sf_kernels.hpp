@@ -236,36 +236,32 @@ __global__ void __launch_bounds__(256) jacobi_kernel(Geom g, JacobiArgs<T, NF> A
     }
 }
 
-// Flat (non-marching) variant: one thread per W cells of one plane, 1-D grid in memory order so the
-// set of lines in flight is a compact moving window (what a plain copy needs to reach ~6.2 TB/s on
-// this part). XCD banding: workgroups are dealt round-robin over the 8 XCDs (b % 8 labels the
-// XCD group), so the j-tiles are cut into 8 contiguous bands and group e only ever works on band
-// e — its j+-1 and k+-1 neighbour lines were fetched by the same XCD and hit in its own 4 MiB L2
-// instead of crossing the fabric. Placement affects speed only, never results.
+// Register-blocked flat sweep (the production Jacobi kernel).
+//   * 1-D grid in memory order, one workgroup = (tx lanes x W cells) x (ty*RJ rows) x RK planes, so the
+//     lines in flight form a compact moving window (what a plain copy needs to reach ~6.2 TB/s here);
+//   * XCD banding: workgroups are dealt round-robin over the 8 XCDs (b % 8 labels the XCD group), so
+//     the j-tiles are cut into 8 contiguous bands and group e only ever works on band e — its j+-1
+//     and k+-1 neighbour lines were fetched by the same XCD and hit in its own 4 MiB L2 instead of
+//     crossing the fabric. Placement affects speed only, never results;
+//   * each thread produces RJ x RK vectors from (RK+2)*RJ + 2*RK loads of x (instead of 5 per
+//     vector) and gets its i+-1 neighbours from the adjacent lanes by wave shuffle — measured, the
+//     two per-lane dword loads for i+-1 cost as much as the k+-1 vector loads;
+//   * the i = 0 / N+1 shell cells are recomputed in registers in all but the first sweep and written
+//     only by the last one (they would cost a whole extra 128-byte line per row end otherwise).
 struct TileMap {
-    int gx;    // tiles along i
-    int gy;    // tiles along j
-    int band;  // j-tiles per XCD band (0: plain order)
-    int nxcd;  // 8 when banded
+    int gx;            // tiles along i
+    int gy;            // tiles along j
+    int band;          // j-tiles per XCD band (0: plain order)
+    int nxcd;          // 8 when banded
+    int ishell_mem;    // read x[0], x[N+1] from memory (first sweep: x is caller data)
+    int ishell_write;  // write the i = 0 / N+1 shell cells of x' (last sweep)
 };
 
-// Sweep flags.
-enum : int {
-    JF_NT_STORE = 1,     // non-temporal stores of x' (working set >> Infinity Cache)
-    JF_ISHELL_MEM = 2,   // read x[0], x[N+1] from memory (first sweep: x is caller data); otherwise they
-                         // are recomputed as sx*x[1], sx*x[N], which is what the previous sweep's fused
-                         // set_bnd stored (or would have stored)
-    JF_ISHELL_WRITE = 4  // write the i = 0 / N+1 shell cells of x' (last sweep, or P > 1 debug)
-};
-
-template <class T, int NF, int FLAGS>
-__global__ void __launch_bounds__(256) jacobi_flat_kernel(Geom g, JacobiArgs<T, NF> A, int kb, int ke,
-                                                           TileMap m) {
+template <class T, int NF, bool NT, int RJ, int RK>
+__global__ void __launch_bounds__(256) jacobi_rb_kernel(Geom g, JacobiArgs<T, NF> A, int kb, int ke,
+                                                         TileMap m) {
     constexpr int W = VecT<T>::W;
     typedef typename VecT<T>::type V;
-    constexpr bool NT = (FLAGS & JF_NT_STORE) != 0;
-    constexpr bool ISHELL_MEM = (FLAGS & JF_ISHELL_MEM) != 0;
-    constexpr bool ISHELL_WRITE = (FLAGS & JF_ISHELL_WRITE) != 0;
     int it, jt, kk, f;
     {
         int r = (int)blockIdx.x;
@@ -282,19 +278,19 @@ __global__ void __launch_bounds__(256) jacobi_flat_kernel(Geom g, JacobiArgs<T, 
             jt = r % m.gy;
             r /= m.gy;
         }
-        const int nk = ke - kb;
-        kk = r % nk;
-        f = r / nk;  // field index: the slowest grid dimension (uniform per workgroup)
+        const int nkg = (ke - kb + RK - 1) / RK;
+        kk = r % nkg;
+        f = r / nkg;  // field index: the slowest grid dimension (uniform per workgroup)
         if (jt >= m.gy) return;
     }
-    const int kl = kb + kk;
+    const int N = g.N;
+    const int k0 = kb + kk * RK;
     const int i0 = 1 + W * (it * (int)blockDim.x + (int)threadIdx.x);
-    const int j = 1 + jt * (int)blockDim.y + (int)threadIdx.y;
-    if (i0 > g.N || j > g.N) return;
-    int nv = g.N - i0 + 1;
+    const int j0 = 1 + (jt * (int)blockDim.y + (int)threadIdx.y) * RJ;
+    if (i0 > N || j0 > N) return;
+    int nv = N - i0 + 1;
     nv = nv > W ? W : nv;
     const T a = A.a, inv = A.inv;
-    const long q = row0(g, j, kl) + i0;
     const T* __restrict__ x = A.x[0];
     const T* __restrict__ x0 = A.x0[0];
     T* __restrict__ xn = A.xn[0];
@@ -307,48 +303,101 @@ __global__ void __launch_bounds__(256) jacobi_flat_kernel(Geom g, JacobiArgs<T, 
             xn = A.xn[ff];
             b = A.b[ff];
         }
-    V c = ldv(x + q);
-    const V km = ldv(x + q - g.plane);
-    const V kp = ldv(x + q + g.plane);
-    const V jm = ldv(x + q - g.px);
-    const V jp = ldv(x + q + g.px);
-    const V s = NT ? __builtin_nontemporal_load(reinterpret_cast<const V*>(x0 + q)) : ldv(x0 + q);
-    T xm, xp;
-    if (ISHELL_MEM) {
-        xm = x[q - 1];
-        xp = x[q + W];
-    } else {
-        const T sx = (b == 1) ? T(-1) : T(1);
-        // interior neighbours come from the adjacent vectors; the two shell cells are recomputed
-        xm = (i0 == 1) ? sx * c[0] : x[q - 1];
-        T last = c[0];
+    const T sx = (b == 1) ? T(-1) : T(1);
+
+    // addresses: rows beyond N+1 / planes beyond ke are clamped (their results are never stored)
+    long rowq[RJ + 2];  // q of rows j0-1 .. j0+RJ in plane 0 (without the plane term)
 #pragma unroll
-        for (int e = 1; e < W; ++e)
-            if (e == nv - 1) last = c[e];
-        xp = (i0 + W - 1 < g.N) ? x[q + W] : sx * last;
-        if (nv < W) {
-            // the shell cell N+1 lies inside this vector: patch it so element nv-1 sees it
+    for (int r = 0; r < RJ + 2; ++r) {
+        int j = j0 - 1 + r;
+        j = j > N + 1 ? N + 1 : j;
+        rowq[r] = (long)j * g.px + (g.lead - 1) + i0;
+    }
+    long planeq[RK + 2];
 #pragma unroll
-            for (int e = 1; e < W; ++e)
-                if (e == nv) c[e] = sx * last;
+    for (int r = 0; r < RK + 2; ++r) {
+        int kl = k0 - 1 + r;
+        kl = kl > ke ? ke : kl;
+        planeq[r] = (long)kl * g.plane;
+    }
+
+    V X[RK + 2][RJ], Jlo[RK], Jhi[RK], S[RK][RJ];
+#pragma unroll
+    for (int r = 0; r < RK + 2; ++r)
+#pragma unroll
+        for (int rj = 0; rj < RJ; ++rj) X[r][rj] = ldv(x + planeq[r] + rowq[rj + 1]);
+#pragma unroll
+    for (int rk = 0; rk < RK; ++rk) {
+        Jlo[rk] = ldv(x + planeq[rk + 1] + rowq[0]);
+        Jhi[rk] = ldv(x + planeq[rk + 1] + rowq[RJ + 1]);
+#pragma unroll
+        for (int rj = 0; rj < RJ; ++rj) {
+            const T* sp = x0 + planeq[rk + 1] + rowq[rj + 1];
+            S[rk][rj] = NT ? __builtin_nontemporal_load(reinterpret_cast<const V*>(sp)) : ldv(sp);
         }
     }
-    T out[W];
+
+    const bool has_left = ((int)threadIdx.x & 63) != 0;
+    const bool has_right = (((int)threadIdx.x + 1) & 63) != 0 && (int)threadIdx.x + 1 < (int)blockDim.x;
+    const bool first_vec = (i0 == 1), last_vec = (i0 + W - 1 >= N);
+
 #pragma unroll
-    for (int e = 0; e < W; ++e) {
-        const T left = (e == 0) ? xm : c[e - 1];
-        const T right = (e == W - 1) ? xp : c[e + 1];
-        out[e] = (s[e] + a * (((left + right) + (jm[e] + jp[e])) + (km[e] + kp[e]))) * inv;
-    }
-    if (NT && nv == W) {
-        V o;
+    for (int rk = 0; rk < RK; ++rk) {
+        const int kl = k0 + rk;
 #pragma unroll
-        for (int e = 0; e < W; ++e) o[e] = out[e];
-        __builtin_nontemporal_store(o, reinterpret_cast<V*>(xn + q));
-    } else {
-        store_cells<T, W>(xn, q - i0, i0, out, nv);
+        for (int rj = 0; rj < RJ; ++rj) {
+            const int j = j0 + rj;
+            V c = X[rk + 1][rj];
+            // i-neighbours: adjacent lanes hold the adjacent vectors (shuffles run on every lane)
+            const T up = __shfl_up(c[W - 1], 1);
+            const T dn = __shfl_down(c[0], 1);
+            if (kl >= ke || j > N) continue;  // wave-uniform for tx >= 64; lanes of other rows otherwise
+            const long q = planeq[rk + 1] + rowq[rj + 1];
+            T last = c[0];
+#pragma unroll
+            for (int e = 1; e < W; ++e)
+                if (e == nv - 1) last = c[e];
+            T xm, xp;
+            if (first_vec)
+                xm = m.ishell_mem ? x[q - 1] : sx * c[0];
+            else
+                xm = has_left ? up : x[q - 1];
+            if (last_vec) {
+                if (m.ishell_mem) {
+                    xp = x[q + W];
+                } else {
+                    xp = sx * last;
+                    if (nv < W) {  // the shell cell N+1 lies inside this vector: patch it
+#pragma unroll
+                        for (int e = 1; e < W; ++e)
+                            if (e == nv) c[e] = sx * last;
+                    }
+                }
+            } else {
+                xp = has_right ? dn : x[q + W];
+            }
+            const V km = X[rk][rj], kp = X[rk + 2][rj];
+            const V jm = (rj == 0) ? Jlo[rk] : X[rk + 1][rj > 0 ? rj - 1 : 0];
+            const V jp = (rj == RJ - 1) ? Jhi[rk] : X[rk + 1][rj < RJ - 1 ? rj + 1 : RJ - 1];
+            const V s = S[rk][rj];
+            T out[W];
+#pragma unroll
+            for (int e = 0; e < W; ++e) {
+                const T left = (e == 0) ? xm : c[e - 1];
+                const T right = (e == W - 1) ? xp : c[e + 1];
+                out[e] = (s[e] + a * (((left + right) + (jm[e] + jp[e])) + (km[e] + kp[e]))) * inv;
+            }
+            if (NT && nv == W) {
+                V o;
+#pragma unroll
+                for (int e = 0; e < W; ++e) o[e] = out[e];
+                __builtin_nontemporal_store(o, reinterpret_cast<V*>(xn + q));
+            } else {
+                store_cells<T, W>(xn, q - i0, i0, out, nv);
+            }
+            emit_shells<T, W>(xn, g, b, i0, j, kl, out, nv, m.ishell_write != 0);
+        }
     }
-    emit_shells<T, W>(xn, g, b, i0, j, kl, out, nv, ISHELL_WRITE);
 }
 
 // ---------------------------------------------------------------------------------------------
