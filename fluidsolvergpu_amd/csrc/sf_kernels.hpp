@@ -400,6 +400,201 @@ __global__ void __launch_bounds__(256) jacobi_rb_kernel(Geom g, JacobiArgs<T, NF
     }
 }
 
+// Two Jacobi sweeps per pass through HBM (temporal blocking, T = 2).
+// x'' = J(J(x)) computed in one kernel: each thread produces RJ x RK output vectors and recomputes, in
+// registers, the first-sweep values y = J(x) on the cross-shaped neighbourhood its outputs need
+// (dist <= 1 around the RJ x RK block; x itself is read at dist <= 2). Redundant first-sweep work is
+// (RJ+2)(RK+2)-4 over RJ*RK vectors (3x at 2x2) — VALU is idle in this bandwidth-bound kernel — while
+// HBM traffic per sweep halves: x, x0 are read once and x'' is written once for two sweeps.
+// The first sweep's set_bnd is applied in registers (y on a wall row/plane is +-y of the adjacent
+// interior row/plane; its i-shell is sx*y[1], sx*y[N]), so the result is bit-identical to two separate
+// sweeps. A workgroup spans whole rows (blockDim.x = ceil(N/W) rounded up to 64); the only values that
+// cross waves are the end cells of y, exchanged through a few words of LDS.
+// Requirements (checked by the launcher): N % W == 0, ceil(N/W) <= 256, one slab (P = 1).
+template <class T, int NF, bool NT, int RJ, int RK>
+__global__ void __launch_bounds__(256) jacobi2_kernel(Geom g, JacobiArgs<T, NF> A, int kb, int ke,
+                                                       TileMap m) {
+    constexpr int W = VecT<T>::W;
+    typedef typename VecT<T>::type V;
+    constexpr int NPOS = RJ * RK;
+    __shared__ T sh_first[4][NPOS];  // [wave][output position]: y of the wave's first cell
+    __shared__ T sh_last[4][NPOS];   //                          y of the wave's last cell
+    int jt, kk, f;
+    {
+        int r = (int)blockIdx.x;
+        if (m.band > 0) {
+            const int xcd = r % m.nxcd;
+            r /= m.nxcd;
+            jt = xcd * m.band + r % m.band;
+            r /= m.band;
+        } else {
+            jt = r % m.gy;
+            r /= m.gy;
+        }
+        const int nkg = (ke - kb + RK - 1) / RK;
+        kk = r % nkg;
+        f = r / nkg;
+    }
+    const int N = g.N;
+    const int nvec = N / W;
+    const int k0 = kb + kk * RK;
+    const bool tile_ok = jt < m.gy;  // uniform per workgroup
+    int vec = (int)threadIdx.x;
+    int j0 = 1 + (jt * (int)blockDim.y + (int)threadIdx.y) * RJ;
+    const bool active = tile_ok && vec < nvec && j0 <= N;
+    // out-of-range threads keep running on clamped (valid) addresses so that every wave reaches the
+    // barrier and every shuffle source lane is alive; they store nothing
+    vec = vec < nvec ? vec : nvec - 1;
+    j0 = (tile_ok && j0 <= N) ? j0 : N;
+    const int i0 = 1 + W * vec;
+    const T a = A.a, inv = A.inv;
+    const T* __restrict__ x = A.x[0];
+    const T* __restrict__ x0 = A.x0[0];
+    T* __restrict__ xn = A.xn[0];
+    int b = A.b[0];
+#pragma unroll
+    for (int ff = 1; ff < NF; ++ff)
+        if (f == ff) {
+            x = A.x[ff];
+            x0 = A.x0[ff];
+            xn = A.xn[ff];
+            b = A.b[ff];
+        }
+    const T sx = (b == 1) ? T(-1) : T(1);
+    const T sy = (b == 2) ? T(-1) : T(1);
+    const T sz = (b == 3) ? T(-1) : T(1);
+
+    // rows j0-2 .. j0+RJ+1 and planes k0-2 .. k0+RK+1, clamped into the stored range
+    long rowq[RJ + 4];
+#pragma unroll
+    for (int r = 0; r < RJ + 4; ++r) {
+        int j = j0 - 2 + r;
+        j = j < 0 ? 0 : (j > N + 1 ? N + 1 : j);
+        rowq[r] = (long)j * g.px + (g.lead - 1) + i0;
+    }
+    long planeq[RK + 4];
+#pragma unroll
+    for (int r = 0; r < RK + 4; ++r) {
+        int kl = k0 - 2 + r;
+        kl = kl < 0 ? 0 : (kl > g.nzl + 1 ? g.nzl + 1 : kl);
+        planeq[r] = (long)kl * g.plane;
+    }
+    // distance of block-local coordinate a in [-2, R+1] from the output range [0, R-1]
+#define SF_DIST(a_, R_) ((a_) < 0 ? -(a_) : ((a_) > (R_)-1 ? (a_) - ((R_)-1) : 0))
+
+    V X[RK + 4][RJ + 4];
+#pragma unroll
+    for (int c = -2; c <= RK + 1; ++c)
+#pragma unroll
+        for (int r = -2; r <= RJ + 1; ++r)
+            if (SF_DIST(c, RK) + SF_DIST(r, RJ) <= 2) X[c + 2][r + 2] = ldv(x + planeq[c + 2] + rowq[r + 2]);
+    V S[RK + 2][RJ + 2];
+#pragma unroll
+    for (int c = -1; c <= RK; ++c)
+#pragma unroll
+        for (int r = -1; r <= RJ; ++r)
+            if (SF_DIST(c, RK) + SF_DIST(r, RJ) <= 1) S[c + 1][r + 1] = ldv(x0 + planeq[c + 2] + rowq[r + 2]);
+
+    const int lane = (int)threadIdx.x & 63;
+    // LDS slot of this wave: rows of the workgroup are stacked, waves of one row are adjacent slots
+    const int wave = (int)threadIdx.y * ((int)blockDim.x >> 6) + ((int)threadIdx.x >> 6);
+    const bool first_vec = (vec == 0), last_vec = (vec == nvec - 1);
+    const bool has_left = lane != 0, has_right = lane != 63;
+
+    // ---- first sweep: y on the cross-shaped neighbourhood -------------------------------------------
+    V Y[RK + 2][RJ + 2];
+#pragma unroll
+    for (int c = -1; c <= RK; ++c)
+#pragma unroll
+        for (int r = -1; r <= RJ; ++r) {
+            if (SF_DIST(c, RK) + SF_DIST(r, RJ) > 1) continue;
+            const V cc = X[c + 2][r + 2];
+            const T up = __shfl_up(cc[W - 1], 1);
+            const T dn = __shfl_down(cc[0], 1);
+            const long q = planeq[c + 2] + rowq[r + 2];
+            T xm, xp;
+            if (first_vec)
+                xm = m.ishell_mem ? x[q - 1] : sx * cc[0];
+            else
+                xm = has_left ? up : x[q - 1];
+            if (last_vec)
+                xp = m.ishell_mem ? x[q + W] : sx * cc[W - 1];
+            else
+                xp = has_right ? dn : x[q + W];
+            const V km = X[c + 1][r + 2], kp = X[c + 3][r + 2];
+            const V jm = X[c + 2][r + 1], jp = X[c + 2][r + 3];
+            const V s = S[c + 1][r + 1];
+            V y;
+#pragma unroll
+            for (int e = 0; e < W; ++e) {
+                const T left = (e == 0) ? xm : cc[e - 1];
+                const T right = (e == W - 1) ? xp : cc[e + 1];
+                y[e] = (s[e] + a * (((left + right) + (jm[e] + jp[e])) + (km[e] + kp[e]))) * inv;
+            }
+            Y[c + 1][r + 1] = y;
+        }
+
+    // ---- end cells of y cross waves through LDS (only when a row is wider than one wave) ---------------
+    const bool multi_wave = blockDim.x > 64;
+    if (multi_wave) {
+#pragma unroll
+        for (int rk = 0; rk < RK; ++rk)
+#pragma unroll
+            for (int rj = 0; rj < RJ; ++rj) {
+                if (lane == 0) sh_first[wave][rk * RJ + rj] = Y[rk + 1][rj + 1][0];
+                if (lane == 63) sh_last[wave][rk * RJ + rj] = Y[rk + 1][rj + 1][W - 1];
+            }
+        __syncthreads();
+    }
+
+    // ---- second sweep --------------------------------------------------------------------------------
+#pragma unroll
+    for (int rk = 0; rk < RK; ++rk) {
+        const int kl = k0 + rk;
+        const int kg = g.kg0 + kl;
+#pragma unroll
+        for (int rj = 0; rj < RJ; ++rj) {
+            const int j = j0 + rj;
+            const V yc = Y[rk + 1][rj + 1];
+            const T up = __shfl_up(yc[W - 1], 1);
+            const T dn = __shfl_down(yc[0], 1);
+            T ym, yp;
+            if (first_vec)
+                ym = sx * yc[0];
+            else
+                ym = has_left ? up : sh_last[wave > 0 ? wave - 1 : 0][rk * RJ + rj];
+            if (last_vec)
+                yp = sx * yc[W - 1];
+            else
+                yp = has_right ? dn : sh_first[wave < 3 ? wave + 1 : 3][rk * RJ + rj];
+            if (!active || kl >= ke || j > N) continue;
+            V jm = Y[rk + 1][rj], jp = Y[rk + 1][rj + 2], km = Y[rk][rj + 1], kp = Y[rk + 2][rj + 1];
+            if (j == 1) jm = sy * yc;
+            if (j == N) jp = sy * yc;
+            if (g.wall_lo && kg == 1) km = sz * yc;
+            if (g.wall_hi && kg == N) kp = sz * yc;
+            const V s = S[rk + 1][rj + 1];
+            T out[W];
+#pragma unroll
+            for (int e = 0; e < W; ++e) {
+                const T left = (e == 0) ? ym : yc[e - 1];
+                const T right = (e == W - 1) ? yp : yc[e + 1];
+                out[e] = (s[e] + a * (((left + right) + (jm[e] + jp[e])) + (km[e] + kp[e]))) * inv;
+            }
+            const long q = planeq[rk + 2] + rowq[rj + 2];
+            V o;
+#pragma unroll
+            for (int e = 0; e < W; ++e) o[e] = out[e];
+            if (NT)
+                __builtin_nontemporal_store(o, reinterpret_cast<V*>(xn + q));
+            else
+                stv(xn + q, o);
+            emit_shells<T, W>(xn, g, b, i0, j, kl, out, W, m.ishell_write != 0);
+        }
+    }
+#undef SF_DIST
+}
+
 // ---------------------------------------------------------------------------------------------
 // advect: semi-Lagrangian back-trace + trilinear interpolation + fused set_bnd (SPEC §3 advect).
 // NF fields share one back-trace (vel_step advects u,v,w through the same velocity).
