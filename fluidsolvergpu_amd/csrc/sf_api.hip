@@ -178,7 +178,10 @@ public:
         nt_mode_ = env_int("SF_NT", 2);
         ishell_skip_ = env_int("SF_ISHELL", 1) != 0;
         rb_shape_ = env_int("SF_RB", 0);
-        fuse2_ = env_int("SF_FUSE2", 1) != 0;
+        // 0 single sweeps, 1 register-only pairs (default), 2 LDS-staged marching pairs (experimental: correct,
+        // but with one 512-thread workgroup per CU it is latency-bound — 305 vs 267 us/sweep at 512^3)
+        fuse2_ = env_int("SF_FUSE2", 1);
+        kc2_ = env_int("SF_KC2", 32);
         tx_override_ = env_int("SF_TX", 0);
         SF_HIP(hipDeviceSynchronize());
     }
@@ -736,10 +739,40 @@ private:
                            sl.geom, A, kb, ke, m);
     }
 
+    // LDS-staged marching form: rows of up to 128 vectors (blockDim = NV x 4 <= 512 threads).
+    bool can_march2() const { return fuse2_ == 2 && N_ / W <= 128 && N_ / W >= 33; }
+
+    template <int NF, bool NT>
+    void launch_march2(Slab& sl, const sfk::JacobiArgs<T, NF>& A, int kb, int ke, bool first, bool last) {
+        constexpr int TJ = 8;
+        const int nvec = N_ / W;
+        const int NV = ceil_div(nvec, 64) * 64;
+        sfk::TileMap m;
+        m.gx = 1;
+        m.gy = ceil_div(N_, TJ);
+        m.nxcd = 8;
+        m.band = (jacobi_mode_ >= 2 && m.gy >= 16) ? ceil_div(m.gy, 8) : 0;
+        m.ishell_mem = (!ishell_skip_ || first) ? 1 : 0;
+        m.ishell_write = (!ishell_skip_ || last) ? 1 : 0;
+        const int kc = std::max(1, std::min(kc2_, ke - kb));
+        const long per_plane = m.band > 0 ? (long)m.nxcd * m.band : (long)m.gy;
+        const long nblocks = per_plane * ceil_div(ke - kb, kc) * NF;
+        const size_t lds = (size_t)2 * (TJ + 4) * NV * sizeof(typename sfk::VecT<T>::type);
+        hipLaunchKernelGGL((sfk::jacobi2m_kernel<T, NF, NT, TJ>), dim3((unsigned)nblocks), dim3(NV, 4), lds, sl.cs,
+                           sl.geom, A, kb, ke, m, kc);
+    }
+
     template <int NF>
     void launch_jacobi2(Slab& sl, const sfk::JacobiArgs<T, NF>& A, int kb, int ke, bool first, bool last) {
         const bool nt = nt_mode_ == 1 ||
                         (nt_mode_ == 2 && (size_t)field_elems_ * sizeof(T) * 3 * NF > ((size_t)384 << 20));
+        if (can_march2()) {
+            if (nt)
+                launch_march2<NF, true>(sl, A, kb, ke, first, last);
+            else
+                launch_march2<NF, false>(sl, A, kb, ke, first, last);
+            return;
+        }
         if (nt)
             launch_fused2<NF, true, 2, 2>(sl, A, kb, ke, first, last);
         else
@@ -852,7 +885,8 @@ private:
     T dt_{}, diff_{}, visc_{};
     int num_cu_ = 256;
     int nzl_ = 0, lead_ = 0, px_ = 0, nplanes_ = 0, kchunk_ = 0, jacobi_mode_ = 2, tx_override_ = 0, nt_mode_ = 2, rb_shape_ = 0;
-    bool ishell_skip_ = true, fuse2_ = true;
+    bool ishell_skip_ = true;
+    int fuse2_ = 1, kc2_ = 32;
     long plane_ = 0, field_elems_ = 0;
     std::vector<Slab> slabs_;
     ncclComm_t comm_ = nullptr;

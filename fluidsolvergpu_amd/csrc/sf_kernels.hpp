@@ -142,6 +142,16 @@ __device__ __forceinline__ void emit_shells(T* __restrict__ f, const Geom& g, in
     }
 }
 
+// Out-of-line form for kernels that are short of registers: only wall-adjacent threads call it.
+template <class T, int W>
+__device__ __attribute__((noinline)) void emit_shells_call(T* __restrict__ f, const Geom& g, int b, int i0,
+                                                           int j, int kl, typename VecT<T>::type o, bool with_i) {
+    T out[W];
+#pragma unroll
+    for (int e = 0; e < W; ++e) out[e] = o[e];
+    emit_shells<T, W>(f, g, b, i0, j, kl, out, W, with_i);
+}
+
 // Thread -> (vector column, row). Returns false if the thread is outside the grid.
 template <int W>
 __device__ __forceinline__ bool thread_cell(const Geom& g, int& i0, int& j, int& nv) {
@@ -593,6 +603,220 @@ __global__ void __launch_bounds__(256) jacobi2_kernel(Geom g, JacobiArgs<T, NF> 
         }
     }
 #undef SF_DIST
+}
+
+// LDS-staged, k-marching form of the two-sweep kernel (2.5-D temporal blocking).
+// A workgroup of NV x 4 threads (NV = vectors per row rounded up to 64) owns TJ output rows of full
+// width and marches `kchunk` planes. Per step it (1) publishes the x rows of plane k+1 (TJ+4 rows,
+// loaded from HBM/L2 exactly once per workgroup) to an LDS tile, (2) computes the first-sweep values
+// y(k+1) on TJ+2 rows — j+-1 from the LDS tile, i+-1 by wave shuffle (LDS only at wave seams),
+// k+-1 from the thread's own registers — and (3) the second-sweep output x''(k) on TJ rows from the
+// y tile of plane k in LDS and y(k-1), y(k), y(k+1) in registers. Loads for the next step are issued
+// before the arithmetic. L2->L1 traffic per output cell and sweep pair: (TJ+4)/TJ of x + (TJ+2)/TJ
+// of x0 (3.0 words at TJ = 8, against ~7.5 for the register-only kernel above); HBM traffic is the
+// compulsory x + x0 + x'' per pair. Walls are handled as in jacobi2_kernel (first-sweep set_bnd
+// applied in registers), so the result is bit-identical to two separate sweeps.
+template <class T, int NF, bool NT, int TJ>
+__global__ void __launch_bounds__(512) jacobi2m_kernel(Geom g, JacobiArgs<T, NF> A, int kb, int ke,
+                                                        TileMap m, int kchunk) {
+    constexpr int W = VecT<T>::W;
+    typedef typename VecT<T>::type V;
+    constexpr int XR = TJ + 4;  // staged rows: tile rows j0-2 .. j0+TJ+1
+    constexpr int RP = 4;       // rows per pass (= blockDim.y)
+    constexpr int NP = XR / RP; // rows per thread
+    static_assert(XR % RP == 0, "TJ + 4 must be a multiple of 4");
+    extern __shared__ __attribute__((aligned(16))) unsigned char sf_smem[];
+    const int NV = (int)blockDim.x;
+    V* __restrict__ Xt = reinterpret_cast<V*>(sf_smem);  // [XR][NV]  x of plane ko+1
+    V* __restrict__ Yt = Xt + XR * NV;                   // [XR][NV]  y of plane ko
+    int jt, kk, f;
+    {
+        int r = (int)blockIdx.x;
+        if (m.band > 0) {
+            const int xcd = r % m.nxcd;
+            r /= m.nxcd;
+            jt = xcd * m.band + r % m.band;
+            r /= m.band;
+        } else {
+            jt = r % m.gy;
+            r /= m.gy;
+        }
+        const int nch = (ke - kb + kchunk - 1) / kchunk;
+        kk = r % nch;
+        f = r / nch;
+    }
+    if (jt >= m.gy) return;  // uniform per workgroup
+    const int N = g.N;
+    const int nvec = N / W;
+    const int k0 = kb + kk * kchunk;
+    const int k1 = (k0 + kchunk < ke) ? k0 + kchunk : ke;
+    const int v = (int)threadIdx.x, h = (int)threadIdx.y, lane = v & 63;
+    const bool vact = v < nvec;
+    const int vc = vact ? v : nvec - 1;  // lanes beyond the row work on a clamped copy, store nothing
+    const int i0 = 1 + W * vc;
+    const int j0 = 1 + jt * TJ;
+    const T a = A.a, inv = A.inv;
+    const T* __restrict__ x = A.x[0];
+    const T* __restrict__ x0 = A.x0[0];
+    T* __restrict__ xn = A.xn[0];
+    int b = A.b[0];
+#pragma unroll
+    for (int ff = 1; ff < NF; ++ff)
+        if (f == ff) {
+            x = A.x[ff];
+            x0 = A.x0[ff];
+            xn = A.xn[ff];
+            b = A.b[ff];
+        }
+    const T sx = (b == 1) ? T(-1) : T(1);
+    const T sy = (b == 2) ? T(-1) : T(1);
+    const T sz = (b == 3) ? T(-1) : T(1);
+    const bool first_vec = (v == 0), last_vec = (v == nvec - 1);
+
+    long rowq[NP];
+    int jrow[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const int j = j0 - 2 + h + RP * p;
+        jrow[p] = j;
+        const int jc = j < 0 ? 0 : (j > N + 1 ? N + 1 : j);
+        rowq[p] = (long)jc * g.px + (g.lead - 1) + i0;
+    }
+    const int kmax = g.nzl + 1;
+    auto planeq = [&](int kl) -> long {
+        kl = kl < 0 ? 0 : (kl > kmax ? kmax : kl);
+        return (long)kl * g.plane;
+    };
+
+    V xA[NP], xB[NP], xC[NP], xD[NP], yA[NP], yB[NP], yC[NP], sB[NP], sC[NP], sD[NP];
+    {
+        const long pa = planeq(k0 - 2), pb = planeq(k0 - 1), pc = planeq(k0);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            xA[p] = ldv(x + pa + rowq[p]);
+            xB[p] = ldv(x + pb + rowq[p]);
+            xC[p] = ldv(x + pc + rowq[p]);
+            sC[p] = ldv(x0 + pb + rowq[p]);
+            sB[p] = sC[p];
+            xD[p] = xC[p];
+            sD[p] = sC[p];
+#pragma unroll
+            for (int e = 0; e < W; ++e) {
+                yA[p][e] = T(0);
+                yB[p][e] = T(0);
+                yC[p][e] = T(0);
+            }
+        }
+    }
+
+    for (int ko = k0 - 2; ko < k1; ++ko) {
+        // (1) publish x(ko+1)
+#pragma unroll
+        for (int p = 0; p < NP; ++p) Xt[(h + RP * p) * NV + v] = xB[p];
+        __syncthreads();
+        // (2) loads for the next step, in flight during the arithmetic below
+        if (ko + 1 < k1) {
+            const long pd = planeq(ko + 3), ps = planeq(ko + 2);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                xD[p] = ldv(x + pd + rowq[p]);
+                sD[p] = ldv(x0 + ps + rowq[p]);
+            }
+        }
+        // (3) first sweep: y(ko+1) on tile rows 1 .. TJ+2
+        const long pq = planeq(ko + 1);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int r = h + RP * p;
+            const int j = jrow[p];
+            if (r < 1 || r > TJ + 2 || j < 1 || j > N) continue;  // uniform per wave
+            const V cc = xB[p];
+            const T up = __shfl_up(cc[W - 1], 1);
+            const T dn = __shfl_down(cc[0], 1);
+            T xm, xp;
+            if (first_vec)
+                xm = m.ishell_mem ? x[pq + rowq[p] - 1] : sx * cc[0];
+            else
+                xm = (lane != 0) ? up : Xt[r * NV + v - 1][W - 1];
+            if (last_vec)
+                xp = m.ishell_mem ? x[pq + rowq[p] + W] : sx * cc[W - 1];
+            else
+                xp = (lane != 63) ? dn : (v + 1 < nvec ? Xt[r * NV + v + 1][0] : cc[W - 1]);
+            const V jm = Xt[(r - 1) * NV + v], jp = Xt[(r + 1) * NV + v];
+            const V km = xA[p], kp = xC[p], s = sC[p];
+            V y;
+#pragma unroll
+            for (int e = 0; e < W; ++e) {
+                const T left = (e == 0) ? xm : cc[e - 1];
+                const T right = (e == W - 1) ? xp : cc[e + 1];
+                y[e] = (s[e] + a * (((left + right) + (jm[e] + jp[e])) + (km[e] + kp[e]))) * inv;
+            }
+            yC[p] = y;
+        }
+        // (4) second sweep: x''(ko) on tile rows 2 .. TJ+1
+        if (ko >= k0) {
+            const int kg = g.kg0 + ko;
+            const long po = planeq(ko);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                const int r = h + RP * p;
+                const int j = jrow[p];
+                if (r < 2 || r > TJ + 1 || j < 1 || j > N) continue;  // uniform per wave
+                const V yc = yB[p];
+                const T up = __shfl_up(yc[W - 1], 1);
+                const T dn = __shfl_down(yc[0], 1);
+                T ym, yp;
+                if (first_vec)
+                    ym = sx * yc[0];
+                else
+                    ym = (lane != 0) ? up : Yt[r * NV + v - 1][W - 1];
+                if (last_vec)
+                    yp = sx * yc[W - 1];
+                else
+                    yp = (lane != 63) ? dn : (v + 1 < nvec ? Yt[r * NV + v + 1][0] : yc[W - 1]);
+                V jm = Yt[(r - 1) * NV + v], jp = Yt[(r + 1) * NV + v];
+                V km = yA[p], kp = yC[p];
+                if (j == 1) jm = sy * yc;
+                if (j == N) jp = sy * yc;
+                if (g.wall_lo && kg == 1) km = sz * yc;
+                if (g.wall_hi && kg == N) kp = sz * yc;
+                const V s = sB[p];
+                T out[W];
+#pragma unroll
+                for (int e = 0; e < W; ++e) {
+                    const T left = (e == 0) ? ym : yc[e - 1];
+                    const T right = (e == W - 1) ? yp : yc[e + 1];
+                    out[e] = (s[e] + a * (((left + right) + (jm[e] + jp[e])) + (km[e] + kp[e]))) * inv;
+                }
+                if (vact) {
+                    const long q = po + rowq[p];
+                    V o;
+#pragma unroll
+                    for (int e = 0; e < W; ++e) o[e] = out[e];
+                    if (NT)
+                        __builtin_nontemporal_store(o, reinterpret_cast<V*>(xn + q));
+                    else
+                        stv(xn + q, o);
+                    const bool near_wall = first_vec | last_vec | (j == 1) | (j == N) |
+                                           (g.wall_lo && kg == 1) | (g.wall_hi && kg == N);
+                    if (near_wall) emit_shells_call<T, W>(xn, g, b, i0, j, ko, o, m.ishell_write != 0);
+                }
+            }
+        }
+        // (5) everyone is done with the y tile of plane ko and the x tile of plane ko+1
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            Yt[(h + RP * p) * NV + v] = yC[p];
+            xA[p] = xB[p];
+            xB[p] = xC[p];
+            xC[p] = xD[p];
+            yA[p] = yB[p];
+            yB[p] = yC[p];
+            sB[p] = sC[p];
+            sC[p] = sD[p];
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
