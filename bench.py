@@ -83,8 +83,9 @@ def words_per_cell_step(K):
 
 
 def time_lin_solve(S, N, dtype, K, reps, device):
-    """Average duration of ONE Jacobi sweep launch (jacobi_kernel, NF = 1) at size N, HIP events on
-    the context's compute stream. Returns (microseconds per launch, min over reps of the same)."""
+    """Average duration of ONE Jacobi kernel launch at size N (NF = 1), HIP events on the context's compute
+    stream around lin_solve(K), divided by the number of launches it issues (sweeps are fused in pairs where
+    the layout allows: sf_lin_solve_launches). Returns (mean us/launch, min us/launch, sweeps per launch)."""
     with S.FluidSolver(N, dtype=dtype, iters=K, device=device) as fs:
         rng = np.random.RandomState(1)
         plane = rng.standard_normal((1, N + 2, N + 2)).astype(fs.np_dtype)
@@ -92,15 +93,16 @@ def time_lin_solve(S, N, dtype, K, reps, device):
             fs.upload_planes("dens", k, plane * (1.0 + 0.001 * k))
             fs.upload_planes("dens0", k, plane * (0.5 - 0.001 * k))
         a, c = 0.3, 1 + 6 * 0.3
+        launches = fs.lin_solve_launches(K)
         fs.lin_solve(0, "dens", "dens0", a, c, 2)  # warm-up
         fs.sync()
         per = []
         for _ in range(reps):
             fs.timer_start()
             fs.lin_solve(0, "dens", "dens0", a, c, K)
-            per.append(fs.timer_stop() * 1e3 / K)
+            per.append(fs.timer_stop() * 1e3 / launches)
         fs.sync()
-        return float(np.mean(per)), float(np.min(per))
+        return float(np.mean(per)), float(np.min(per)), K / launches
 
 
 def cpu_baseline(N, K, dtype, steps, dt, diff, visc):
@@ -221,28 +223,25 @@ def main():
         # ---- roofline leg: the Jacobi sweep, per launch, HIP events on the launch stream -------
         n_local = N if world == 1 else WEAK_GRID[1]
         wsize = 4 if args.dtype == "f32" else 8
-        traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get(f"jacobi_nf1_{args.dtype}_{n_local}")
-        us, us_min = time_lin_solve(S, n_local, args.dtype, K, 5, local_rank)
-        alg = float(n_local) ** 3 * 3 * wsize
-        out["roofline"] = {"bound": "hbm", "kernel": "jacobi_kernel<T,1> (lin_solve sweep + fused set_bnd)",
-                           "achieved": alg / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                           "frac": alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, "traffic": traffic,
-                           "grid": n_local, "us_per_launch": us, "us_per_launch_min": us_min,
-                           "algorithmic_bytes_per_launch": alg,
-                           "note": "3 words/cell/iteration; 256^3 working set (~240 MB) sits largely in the "
-                                   "256 MiB Infinity Cache, see roofline_hbm for the out-of-cache size"}
+        def roofline_entry(n):
+            us, us_min, spl = time_lin_solve(S, n, args.dtype, K, 5 if n <= 256 else 3, local_rank)
+            alg = float(n) ** 3 * 3 * wsize * spl  # 3 words per cell per sweep x sweeps per launch
+            tr = traffic.get(f"jacobi_nf1_{args.dtype}_{n}")
+            return {"bound": "hbm", "kernel": "jacobi2_kernel<T,1,*,2,2>: two fused lin_solve sweeps + set_bnd per launch"
+                    if spl == 2 else "jacobi_rb_kernel<T,1,*>: one lin_solve sweep + set_bnd per launch",
+                    "achieved": alg / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, "traffic": tr, "grid": n,
+                    "us_per_launch": us, "us_per_launch_min": us_min, "sweeps_per_launch": spl,
+                    "algorithmic_bytes_per_launch": alg}
+
+        traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}
+        out["roofline"] = roofline_entry(n_local)
+        out["roofline"]["note"] = ("algorithmic bytes = 3 words/cell/sweep x sweeps per launch; fusing two sweeps halves "
+                                   "the HBM traffic per sweep (see traffic), and the 256^3 working set (~240 MB) sits "
+                                   "largely in the 256 MiB Infinity Cache — roofline_hbm is the 512^3 figure")
         if args.roofline_n and args.roofline_n != n_local:
-            n2 = args.roofline_n
-            us2, us2_min = time_lin_solve(S, n2, args.dtype, K, 3, local_rank)
-            alg2 = float(n2) ** 3 * 3 * wsize
-            t2 = json.load(open(tpath)).get(f"jacobi_nf1_{args.dtype}_{n2}") if os.path.exists(tpath) else None
-            out["roofline_hbm"] = {"bound": "hbm", "achieved": alg2 / (us2 * 1e-6) / 1e9, "peak": HBM_PEAK_GBPS,
-                                   "unit": "GB/s", "frac": alg2 / (us2 * 1e-6) / 1e9 / HBM_PEAK_GBPS,
-                                   "traffic": t2, "grid": n2, "us_per_launch": us2, "us_per_launch_min": us2_min,
-                                   "algorithmic_bytes_per_launch": alg2}
+            out["roofline_hbm"] = roofline_entry(args.roofline_n)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(N, K, args.dtype, args.cpu_steps, dt, diff, visc)
         print(json.dumps(out), flush=True)

@@ -89,6 +89,7 @@ public:
     virtual float timer_stop() = 0;
     virtual double copy_bandwidth(size_t bytes, int reps) = 0;
     virtual void layout_info(int* pitch, int* planes, size_t* bytes) const = 0;
+    virtual int lin_solve_launches(int iters) const = 0;
 };
 
 template <class T>
@@ -487,6 +488,8 @@ public:
         return 2.0 * (double)bytes / (best_ms * 1e-3) / 1e9;
     }
 
+    int lin_solve_launches(int iters) const override { return can_fuse2() ? iters / 2 + iters % 2 : iters; }
+
     void layout_info(int* pitch, int* planes, size_t* bytes) const override {
         if (pitch) *pitch = px_;
         if (planes) *planes = nplanes_;
@@ -566,6 +569,25 @@ private:
         t.kchunk = kchunk;
         t.grid = dim3(gx, gy, ceil_div(nplanes, kchunk));
         return t;
+    }
+
+    // 1-D banded grid for the one-vector-per-thread kernels: fills block, returns the map and block count.
+    sfk::TileMap flat_map(int nplanes, dim3& block, unsigned& nblocks) const {
+        const int nvec = ceil_div(N_, W);
+        int tx = 1;
+        while (tx < nvec && tx < 64) tx <<= 1;
+        const int ty = 256 / tx;
+        block = dim3(tx, ty, 1);
+        sfk::TileMap m;
+        m.gx = ceil_div(nvec, tx);
+        m.gy = ceil_div(N_, ty);
+        m.nxcd = 8;
+        m.band = (jacobi_mode_ >= 2 && m.gy >= 16) ? ceil_div(m.gy, 8) : 0;
+        m.ishell_mem = 1;
+        m.ishell_write = 1;
+        const long per_plane = m.band > 0 ? (long)m.nxcd * m.gx * m.band : (long)m.gx * m.gy;
+        nblocks = (unsigned)(per_plane * nplanes);
+        return m;
     }
 
     // Runs `launch(slab, kb, ke)` over the interior planes of every slab. With P > 1 the two
@@ -840,8 +862,10 @@ private:
             A.w = sl.field[w];
             A.dt0 = dt0;
             A.flag = sl.d_flag;
-            const Tile t = tile(ke - kb, false);
-            hipLaunchKernelGGL((sfk::advect_kernel<T, NF>), t.grid, t.block, 0, sl.cs, sl.geom, A, kb, ke);
+            dim3 block;
+            unsigned nblocks;
+            const sfk::TileMap m = flat_map(ke - kb, block, nblocks);
+            hipLaunchKernelGGL((sfk::advect_kernel<T, NF>), dim3(nblocks), block, 0, sl.cs, sl.geom, A, kb, ke, m);
         });
         exchange<NF>(d);
     }
@@ -865,16 +889,20 @@ private:
             SF_HIP(hipMemsetAsync(sl.field[p], 0, (size_t)field_elems_ * sizeof(T), sl.cs));
         }
         for_planes([&](Slab& sl, int kb, int ke) {
-            const Tile t = tile(ke - kb, false);
-            hipLaunchKernelGGL((sfk::project_div_kernel<T>), t.grid, t.block, 0, sl.cs, sl.geom, args(sl), kb, ke);
+            dim3 block;
+            unsigned nblocks;
+            const sfk::TileMap m = flat_map(ke - kb, block, nblocks);
+            hipLaunchKernelGGL((sfk::project_div_kernel<T>), dim3(nblocks), block, 0, sl.cs, sl.geom, args(sl), kb, ke, m);
         });
         // no exchange here: lin_solve reads div only at cell centres, and p is zero, ghosts included
         const int dv[1] = {div};
         const int ps[1] = {p}, b0[1] = {0};
         op_lin_solve<1>(ps, dv, b0, T(1), T(6), K_);
         for_planes([&](Slab& sl, int kb, int ke) {
-            const Tile t = tile(ke - kb, false);
-            hipLaunchKernelGGL((sfk::project_sub_kernel<T>), t.grid, t.block, 0, sl.cs, sl.geom, args(sl), kb, ke);
+            dim3 block;
+            unsigned nblocks;
+            const sfk::TileMap m = flat_map(ke - kb, block, nblocks);
+            hipLaunchKernelGGL((sfk::project_sub_kernel<T>), dim3(nblocks), block, 0, sl.cs, sl.geom, args(sl), kb, ke, m);
         });
         const int uvw[3] = {u, v, w};
         exchange<3>(uvw);
@@ -1049,6 +1077,10 @@ int sf_measure_copy_bandwidth(sf_ctx* ctx, size_t bytes, int reps, double* gbps)
         const double r = s.copy_bandwidth(bytes, reps);
         if (gbps) *gbps = r;
     });
+}
+int sf_lin_solve_launches(const sf_ctx* ctx, int iters) {
+    if (!ctx || !ctx->impl || iters < 0) return -1;
+    return ctx->impl->lin_solve_launches(iters);
 }
 int sf_layout_info(const sf_ctx* ctx, int* row_pitch, int* planes_per_slab, size_t* bytes_per_field) {
     if (!ctx || !ctx->impl) return SF_ERR_INVALID;

@@ -267,6 +267,42 @@ struct TileMap {
     int ishell_write;  // write the i = 0 / N+1 shell cells of x' (last sweep)
 };
 
+// Workgroup -> (i-tile, j-tile, plane, extra) for the 1-D banded grid. Returns false for padding tiles.
+__device__ __forceinline__ bool flat_tile(const TileMap& m, int nk, int& it, int& jt, int& kk, int& f) {
+    int r = (int)blockIdx.x;
+    if (m.band > 0) {
+        const int xcd = r % m.nxcd;
+        r /= m.nxcd;
+        it = r % m.gx;
+        r /= m.gx;
+        jt = xcd * m.band + r % m.band;
+        r /= m.band;
+    } else {
+        it = r % m.gx;
+        r /= m.gx;
+        jt = r % m.gy;
+        r /= m.gy;
+    }
+    kk = r % nk;
+    f = r / nk;
+    return jt < m.gy;
+}
+
+// Thread -> first cell, row and plane for the one-vector-per-thread kernels on the flat grid.
+template <int W>
+__device__ __forceinline__ bool flat_cell(const Geom& g, const TileMap& m, int kb, int ke, int& i0, int& j,
+                                          int& kl, int& nv) {
+    int it, jt, kk, f;
+    if (!flat_tile(m, ke - kb, it, jt, kk, f)) return false;
+    kl = kb + kk;
+    i0 = 1 + W * (it * (int)blockDim.x + (int)threadIdx.x);
+    j = 1 + jt * (int)blockDim.y + (int)threadIdx.y;
+    if (i0 > g.N || j > g.N) return false;
+    nv = g.N - i0 + 1;
+    nv = nv > W ? W : nv;
+    return true;
+}
+
 template <class T, int NF, bool NT, int RJ, int RK>
 __global__ void __launch_bounds__(256) jacobi_rb_kernel(Geom g, JacobiArgs<T, NF> A, int kb, int ke,
                                                          TileMap m) {
@@ -836,13 +872,12 @@ struct AdvectArgs {
 };
 
 template <class T, int NF>
-__global__ void __launch_bounds__(256) advect_kernel(Geom g, AdvectArgs<T, NF> A, int kb, int ke) {
+__global__ void __launch_bounds__(256) advect_kernel(Geom g, AdvectArgs<T, NF> A, int kb, int ke, TileMap m) {
     constexpr int W = VecT<T>::W;
     typedef typename VecT<T>::type V;
-    int i0, j, nv;
-    if (!thread_cell<W>(g, i0, j, nv)) return;
-    const int kl = kb + (int)blockIdx.z;
-    if (kl >= ke) return;
+    typedef T Pair __attribute__((ext_vector_type(2), aligned(sizeof(T))));
+    int i0, j, kl, nv;
+    if (!flat_cell<W>(g, m, kb, ke, i0, j, kl, nv)) return;
     const int N = g.N;
     const T Nf = (T)N;
     const T lo = T(0.5), hi = Nf + T(0.5);
@@ -886,9 +921,13 @@ __global__ void __launch_bounds__(256) advect_kernel(Geom g, AdvectArgs<T, NF> A
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
             const T* __restrict__ d0 = A.d0[f];
-            out[f][e] = s0 * (t0 * (r0 * d0[p00] + r1 * d0[p01]) + t1 * (r0 * d0[p10] + r1 * d0[p11])) +
-                        s1 * (t0 * (r0 * d0[p00 + 1] + r1 * d0[p01 + 1]) +
-                              t1 * (r0 * d0[p10 + 1] + r1 * d0[p11 + 1]));
+            // the i0 / i0+1 samples are adjacent in memory: one element-aligned two-wide load per corner pair
+            const Pair c00 = *reinterpret_cast<const Pair*>(d0 + p00);
+            const Pair c01 = *reinterpret_cast<const Pair*>(d0 + p01);
+            const Pair c10 = *reinterpret_cast<const Pair*>(d0 + p10);
+            const Pair c11 = *reinterpret_cast<const Pair*>(d0 + p11);
+            out[f][e] = s0 * (t0 * (r0 * c00[0] + r1 * c01[0]) + t1 * (r0 * c10[0] + r1 * c11[0])) +
+                        s1 * (t0 * (r0 * c00[1] + r1 * c01[1]) + t1 * (r0 * c10[1] + r1 * c11[1]));
         }
     }
     if (bad) atomicOr(A.flag, 1);
@@ -913,13 +952,12 @@ struct ProjectArgs {
 };
 
 template <class T>
-__global__ void __launch_bounds__(256) project_div_kernel(Geom g, ProjectArgs<T> A, int kb, int ke) {
+__global__ void __launch_bounds__(256) project_div_kernel(Geom g, ProjectArgs<T> A, int kb, int ke,
+                                                          TileMap m) {
     constexpr int W = VecT<T>::W;
     typedef typename VecT<T>::type V;
-    int i0, j, nv;
-    if (!thread_cell<W>(g, i0, j, nv)) return;
-    const int kl = kb + (int)blockIdx.z;
-    if (kl >= ke) return;
+    int i0, j, kl, nv;
+    if (!flat_cell<W>(g, m, kb, ke, i0, j, kl, nv)) return;
     const long q = row0(g, j, kl) + i0;
     const V uc = ldv(A.u + q);
     const T um = A.u[q - 1], up = A.u[q + W];
@@ -938,13 +976,12 @@ __global__ void __launch_bounds__(256) project_div_kernel(Geom g, ProjectArgs<T>
 
 // project, second half: u -= c_grad*dp/di etc., set_bnd(1,u), (2,v), (3,w).
 template <class T>
-__global__ void __launch_bounds__(256) project_sub_kernel(Geom g, ProjectArgs<T> A, int kb, int ke) {
+__global__ void __launch_bounds__(256) project_sub_kernel(Geom g, ProjectArgs<T> A, int kb, int ke,
+                                                          TileMap m) {
     constexpr int W = VecT<T>::W;
     typedef typename VecT<T>::type V;
-    int i0, j, nv;
-    if (!thread_cell<W>(g, i0, j, nv)) return;
-    const int kl = kb + (int)blockIdx.z;
-    if (kl >= ke) return;
+    int i0, j, kl, nv;
+    if (!flat_cell<W>(g, m, kb, ke, i0, j, kl, nv)) return;
     const long q = row0(g, j, kl) + i0;
     const T* __restrict__ p = A.p;
     const V pc = ldv(p + q);

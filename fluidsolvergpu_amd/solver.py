@@ -29,7 +29,7 @@ ABI_SYMBOLS = (
     "sf_download", "sf_download_planes", "sf_upload_planes", "sf_owned_planes", "sf_fill", "sf_copy_field", "vel_step",
     "dens_step", "sf_add_source", "sf_set_bnd", "sf_lin_solve", "sf_diffuse", "sf_advect", "sf_project",
     "sf_set_iters", "sf_set_coefficients", "sf_sync", "sf_last_error", "sf_timer_start", "sf_timer_stop",
-    "sf_measure_copy_bandwidth", "sf_layout_info",
+    "sf_measure_copy_bandwidth", "sf_layout_info", "sf_lin_solve_launches",
 )
 
 
@@ -70,6 +70,7 @@ lib.sf_sync.argtypes = [_ctx]
 lib.sf_timer_start.argtypes = [_ctx]
 lib.sf_timer_stop.argtypes = [_ctx, C.POINTER(C.c_float)]
 lib.sf_measure_copy_bandwidth.argtypes = [_ctx, C.c_size_t, C.c_int, C.POINTER(C.c_double)]
+lib.sf_lin_solve_launches.argtypes = [_ctx, C.c_int]
 lib.sf_layout_info.argtypes = [_ctx, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_size_t)]
 
 
@@ -227,6 +228,9 @@ class FluidSolver:
         g = C.c_double()
         self._ck(lib.sf_measure_copy_bandwidth(self._h, int(nbytes), int(reps), C.byref(g)))
         return g.value
+
+    def lin_solve_launches(self, iters):
+        return int(lib.sf_lin_solve_launches(self._h, int(iters)))
 
     def layout_info(self):
         pitch, planes, nbytes = C.c_int(), C.c_int(), C.c_size_t()

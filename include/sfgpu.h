@@ -130,6 +130,11 @@ int sf_timer_stop(sf_ctx* ctx, float* ms);
  * traffic. Used by bench.py to quote the achievable-HBM figure in the same run. */
 int sf_measure_copy_bandwidth(sf_ctx* ctx, size_t bytes, int reps, double* gbps);
 
+/* Number of kernel launches sf_lin_solve(..., iters) issues per field group on this context: sweeps are
+ * fused in pairs where the layout allows (docs: DESIGN.md §4), so this is iters/2 (+1 if odd) or iters.
+ * Lets a benchmark convert a lin_solve time into a per-launch time comparable with rocprof. */
+int sf_lin_solve_launches(const sf_ctx* ctx, int iters);
+
 /* Geometry of the internal layout, for reports: row pitch (elements), planes stored per slab,
  * bytes per field per slab. Any pointer may be NULL. */
 int sf_layout_info(const sf_ctx* ctx, int* row_pitch, int* planes_per_slab, size_t* bytes_per_field);
