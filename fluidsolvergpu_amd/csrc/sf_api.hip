@@ -72,6 +72,7 @@ public:
     virtual void download_planes(int field, int kb, int ke, void* host) = 0;
     virtual void upload_planes(int field, int kb, int ke, const void* host) = 0;
     virtual void owned_planes(int* kb, int* ke) const = 0;
+    virtual void stored_planes(int* kb, int* ke) const = 0;
     virtual void fill(int field, double value) = 0;
     virtual void copy_field(int dst, int src) = 0;
     virtual void vel_step() = 0;
@@ -140,7 +141,9 @@ public:
         const int line = 128 / (int)sizeof(T);
         px_ = ceil_div(lead_ + N_ + 1 + W, line) * line;
         plane_ = (long)px_ * (N_ + 2);
-        nplanes_ = nzl_ + 2;
+        // two ghost planes per side let sweep pairs be fused across slab boundaries (one exchange per pair)
+        G_ = (P_ > 1 && nzl_ >= 2 && env_int("SF_GHOST", 2) >= 2) ? 2 : 1;
+        nplanes_ = nzl_ + 2 * G_;
         field_elems_ = plane_ * nplanes_ + 256;  // slack so whole-vector accesses never leave the buffer
         field_elems_ = (field_elems_ + W - 1) / W * W;
 
@@ -150,7 +153,9 @@ public:
             sl.gid = rank_ * L_ + s;
             sl.geom.N = N_;
             sl.geom.nzl = nzl_;
-            sl.geom.kg0 = sl.gid * nzl_;  // first interior k = gid*nzl + 1
+            sl.geom.G = G_;
+            sl.geom.np = nplanes_;
+            sl.geom.kg0 = sl.gid * nzl_ + 1 - G_;  // first interior k = gid*nzl + 1 is local plane G
             sl.geom.px = px_;
             sl.geom.lead = lead_;
             sl.geom.plane = plane_;
@@ -216,11 +221,11 @@ public:
         const size_t S = (size_t)N_ + 2;
         for (Slab& sl : slabs_) {
             T* dev = ensure(sl, field);
-            // every stored plane (ghosts included) comes from the global array
-            const int kg_first = sl.geom.kg0;  // local plane 0
-            const T* src = static_cast<const T*>(host) + (size_t)kg_first * S * S;
-            SF_HIP(hipMemcpy2DAsync(dev + (lead_ - 1), (size_t)px_ * sizeof(T), src, S * sizeof(T),
-                                    S * sizeof(T), S * (size_t)nplanes_, hipMemcpyHostToDevice, sl.cs));
+            // every stored plane that exists globally (ghosts included) comes from the global array
+            const int gb = std::max(sl.geom.kg0, 0), ge = std::min(sl.geom.kg0 + nplanes_, N_ + 2);
+            const T* src = static_cast<const T*>(host) + (size_t)gb * S * S;
+            SF_HIP(hipMemcpy2DAsync(dev + (size_t)(gb - sl.geom.kg0) * plane_ + (lead_ - 1), (size_t)px_ * sizeof(T), src,
+                                    S * sizeof(T), S * sizeof(T), S * (size_t)(ge - gb), hipMemcpyHostToDevice, sl.cs));
         }
         for (Slab& sl : slabs_) SF_HIP(hipStreamSynchronize(sl.cs));
     }
@@ -229,8 +234,8 @@ public:
         check_field(field);
         SF_REQUIRE(host != nullptr, "null host pointer");
         for (Slab& sl : slabs_) {
-            const int kb = sl.geom.kg0 + 1 - (sl.geom.wall_lo ? 1 : 0);
-            const int ke = sl.geom.kg0 + nzl_ + 1 + (sl.geom.wall_hi ? 1 : 0);
+            const int kb = sl.geom.kg0 + G_ - (sl.geom.wall_lo ? 1 : 0);
+            const int ke = sl.geom.kg0 + G_ + nzl_ + (sl.geom.wall_hi ? 1 : 0);
             const size_t S = (size_t)N_ + 2;
             copy_planes_out(sl, field, kb, ke, static_cast<T*>(host) + (size_t)kb * S * S);
         }
@@ -245,8 +250,8 @@ public:
         bool any = false;
         for (Slab& sl : slabs_) {
             // planes of [kb,ke) this slab is the owner of (interior; shell planes on wall slabs)
-            const int ob = sl.geom.kg0 + 1 - (sl.geom.wall_lo ? 1 : 0);
-            const int oe = sl.geom.kg0 + nzl_ + 1 + (sl.geom.wall_hi ? 1 : 0);
+            const int ob = sl.geom.kg0 + G_ - (sl.geom.wall_lo ? 1 : 0);
+            const int oe = sl.geom.kg0 + G_ + nzl_ + (sl.geom.wall_hi ? 1 : 0);
             const int b = std::max(kb, ob), e = std::min(ke, oe);
             if (b >= e) continue;
             any = true;
@@ -265,7 +270,8 @@ public:
         bool any = false;
         for (Slab& sl : slabs_) {
             T* dev = ensure(sl, field);
-            const int b = std::max(kb, sl.geom.kg0), e = std::min(ke, sl.geom.kg0 + nplanes_);
+            const int b = std::max(std::max(kb, sl.geom.kg0), 0);
+            const int e = std::min(std::min(ke, sl.geom.kg0 + nplanes_), N_ + 2);
             if (b >= e) continue;
             any = true;
             const T* src = static_cast<const T*>(host) + (size_t)(b - kb) * S * S;
@@ -277,9 +283,14 @@ public:
         for (Slab& sl : slabs_) SF_HIP(hipStreamSynchronize(sl.cs));
     }
 
+    void stored_planes(int* kb, int* ke) const override {
+        if (kb) *kb = std::max(slabs_.front().geom.kg0, 0);
+        if (ke) *ke = std::min(slabs_.back().geom.kg0 + nplanes_, N_ + 2);
+    }
+
     void owned_planes(int* kb, int* ke) const override {
-        if (kb) *kb = slabs_.front().geom.kg0 + 1;
-        if (ke) *ke = slabs_.back().geom.kg0 + nzl_ + 1;
+        if (kb) *kb = slabs_.front().geom.kg0 + G_;
+        if (ke) *ke = slabs_.back().geom.kg0 + G_ + nzl_;
     }
 
     void fill(int field, double value) override {
@@ -594,17 +605,23 @@ private:
     // slab-boundary planes go first, their completion is recorded, and the rest follows so that the
     // halo exchange issued by the caller overlaps the interior work.
     template <class F>
-    void for_planes(F launch) {
+    void for_planes(F launch, int depth = 1) {
+        const int kb = G_, ke = G_ + nzl_;
         if (P_ == 1) {
-            launch(slabs_[0], 1, nzl_ + 1);
+            launch(slabs_[0], kb, ke);
             SF_HIP(hipGetLastError());
             return;
         }
         for (Slab& sl : slabs_) {
-            launch(sl, 1, 2);
-            if (nzl_ >= 2) launch(sl, nzl_, nzl_ + 1);
-            SF_HIP(hipEventRecord(sl.boundary_done, sl.cs));
-            if (nzl_ > 2) launch(sl, 2, nzl_);
+            if (nzl_ <= 2 * depth) {
+                launch(sl, kb, ke);
+                SF_HIP(hipEventRecord(sl.boundary_done, sl.cs));
+            } else {
+                launch(sl, kb, kb + depth);
+                launch(sl, ke - depth, ke);
+                SF_HIP(hipEventRecord(sl.boundary_done, sl.cs));
+                launch(sl, kb + depth, ke - depth);
+            }
         }
         SF_HIP(hipGetLastError());
     }
@@ -614,7 +631,11 @@ private:
     template <int NF>
     void exchange(const int (&fields)[NF]) {
         if (P_ == 1) return;
-        const size_t bytes = (size_t)plane_ * sizeof(T);
+        // G_ planes per direction: the first / last G_ interior planes go to the neighbour's ghost planes
+        const size_t gcount = (size_t)G_ * plane_;
+        const size_t bytes = gcount * sizeof(T);
+        const size_t send_lo = (size_t)G_ * plane_, send_hi = (size_t)nzl_ * plane_;
+        const size_t recv_lo = 0, recv_hi = (size_t)(G_ + nzl_) * plane_;
         for (int s = 0; s < L_; ++s) {
             Slab& sl = slabs_[s];
             SF_HIP(hipStreamWaitEvent(sl.hs, sl.boundary_done, 0));
@@ -626,11 +647,10 @@ private:
             for (int f = 0; f < NF; ++f) {
                 T* mine = sl.field[fields[f]];
                 if (lo_local)
-                    SF_HIP(hipMemcpyAsync(mine, slabs_[s - 1].field[fields[f]] + (size_t)nzl_ * plane_, bytes,
+                    SF_HIP(hipMemcpyAsync(mine + recv_lo, slabs_[s - 1].field[fields[f]] + send_hi, bytes,
                                           hipMemcpyDeviceToDevice, sl.hs));
                 if (hi_local)
-                    SF_HIP(hipMemcpyAsync(mine + (size_t)(nzl_ + 1) * plane_,
-                                          slabs_[s + 1].field[fields[f]] + (size_t)plane_, bytes,
+                    SF_HIP(hipMemcpyAsync(mine + recv_hi, slabs_[s + 1].field[fields[f]] + send_lo, bytes,
                                           hipMemcpyDeviceToDevice, sl.hs));
             }
             // neighbours in other processes: grouped send/recv over RCCL (xGMI point-to-point)
@@ -641,13 +661,12 @@ private:
                 for (int f = 0; f < NF; ++f) {
                     T* mine = sl.field[fields[f]];
                     if (lo_remote) {
-                        SF_NCCL(ncclSend(mine + (size_t)plane_, (size_t)plane_, dt, rank_ - 1, comm_, sl.hs));
-                        SF_NCCL(ncclRecv(mine, (size_t)plane_, dt, rank_ - 1, comm_, sl.hs));
+                        SF_NCCL(ncclSend(mine + send_lo, gcount, dt, rank_ - 1, comm_, sl.hs));
+                        SF_NCCL(ncclRecv(mine + recv_lo, gcount, dt, rank_ - 1, comm_, sl.hs));
                     }
                     if (hi_remote) {
-                        SF_NCCL(ncclSend(mine + (size_t)nzl_ * plane_, (size_t)plane_, dt, rank_ + 1, comm_, sl.hs));
-                        SF_NCCL(ncclRecv(mine + (size_t)(nzl_ + 1) * plane_, (size_t)plane_, dt, rank_ + 1, comm_,
-                                         sl.hs));
+                        SF_NCCL(ncclSend(mine + send_hi, gcount, dt, rank_ + 1, comm_, sl.hs));
+                        SF_NCCL(ncclRecv(mine + recv_hi, gcount, dt, rank_ + 1, comm_, sl.hs));
                     }
                 }
                 SF_NCCL(ncclGroupEnd());
@@ -741,7 +760,9 @@ private:
     // Two fused sweeps (temporal blocking). Usable when a row fits one workgroup, N is a multiple of the
     // vector width and the grid is not decomposed (a second ghost plane would be needed).
     // (measured: +5 % at 512^3, +12 % at 256^3, -8 % at 1024^3 where a row spans four waves -> rows <= 128 vectors)
-    bool can_fuse2() const { return fuse2_ && P_ == 1 && N_ % W == 0 && N_ / W <= 128 && jacobi_mode_ != 0; }
+    bool can_fuse2() const {
+        return fuse2_ && (P_ == 1 || G_ == 2) && N_ % W == 0 && N_ / W <= 128 && jacobi_mode_ != 0;
+    }
 
     template <int NF, bool NT, int RJ, int RK>
     void launch_fused2(Slab& sl, const sfk::JacobiArgs<T, NF>& A, int kb, int ke, bool first, bool last) {
@@ -762,7 +783,7 @@ private:
     }
 
     // LDS-staged marching form: rows of up to 128 vectors (blockDim = NV x 4 <= 512 threads).
-    bool can_march2() const { return fuse2_ == 2 && N_ / W <= 128 && N_ / W >= 33; }
+    bool can_march2() const { return fuse2_ == 2 && P_ == 1 && N_ / W <= 128 && N_ / W >= 33; }
 
     template <int NF, bool NT>
     void launch_march2(Slab& sl, const sfk::JacobiArgs<T, NF>& A, int kb, int ke, bool first, bool last) {
@@ -829,7 +850,7 @@ private:
                     launch_jacobi2<NF>(sl, A, kb, ke, it == 0, it + step == K);
                 else
                     launch_jacobi<NF>(sl, A, kb, ke, it == 0, it + step == K);
-            });
+            }, step);
             // the new iterate becomes the field; the old buffer becomes scratch
             for (Slab& sl : slabs_)
                 for (int f = 0; f < NF; ++f) std::swap(sl.field[x[f]], sl.scratch[f]);
@@ -888,12 +909,18 @@ private:
             ensure(sl, p);
             SF_HIP(hipMemsetAsync(sl.field[p], 0, (size_t)field_elems_ * sizeof(T), sl.cs));
         }
-        for_planes([&](Slab& sl, int kb, int ke) {
+        // div is also evaluated on the first ghost plane either side (not on physical shells) when sweep pairs
+        // are fused across slabs: the fused kernel's first sweep needs x0 = div there, and recomputing it from
+        // the depth-2 ghosts of u,v,w is cheaper than another exchange. No exchange follows, so one launch.
+        for (Slab& sl : slabs_) {
+            const int kb = G_ - ((G_ == 2 && !sl.geom.wall_lo) ? 1 : 0);
+            const int ke = G_ + nzl_ + ((G_ == 2 && !sl.geom.wall_hi) ? 1 : 0);
             dim3 block;
             unsigned nblocks;
             const sfk::TileMap m = flat_map(ke - kb, block, nblocks);
             hipLaunchKernelGGL((sfk::project_div_kernel<T>), dim3(nblocks), block, 0, sl.cs, sl.geom, args(sl), kb, ke, m);
-        });
+        }
+        SF_HIP(hipGetLastError());
         // no exchange here: lin_solve reads div only at cell centres, and p is zero, ghosts included
         const int dv[1] = {div};
         const int ps[1] = {p}, b0[1] = {0};
@@ -909,7 +936,7 @@ private:
     }
 
     int N_, K_, device_;
-    int L_ = 1, nranks_ = 1, rank_ = 0, P_ = 1;
+    int L_ = 1, nranks_ = 1, rank_ = 0, P_ = 1, G_ = 1;
     T dt_{}, diff_{}, visc_{};
     int num_cu_ = 256;
     int nzl_ = 0, lead_ = 0, px_ = 0, nplanes_ = 0, kchunk_ = 0, jacobi_mode_ = 2, tx_override_ = 0, nt_mode_ = 2, rb_shape_ = 0;
@@ -1014,6 +1041,11 @@ int sf_download_planes(sf_ctx* ctx, int field, int k_begin, int k_end, void* hos
 }
 int sf_upload_planes(sf_ctx* ctx, int field, int k_begin, int k_end, const void* host) {
     return guarded(ctx, [&](SolverBase& s) { s.upload_planes(field, k_begin, k_end, host); });
+}
+int sf_stored_planes(const sf_ctx* ctx, int* k_begin, int* k_end) {
+    if (!ctx || !ctx->impl) return SF_ERR_INVALID;
+    ctx->impl->stored_planes(k_begin, k_end);
+    return SF_OK;
 }
 int sf_owned_planes(const sf_ctx* ctx, int* k_begin, int* k_end) {
     if (!ctx || !ctx->impl) return SF_ERR_INVALID;

@@ -6,7 +6,7 @@
 // is the reference's `buffer = GRIDSIZE*GRIDSIZE` (solver-unidyn.cu:187).
 //
 // Device layout of one field of one slab (element type T, W = 16/sizeof(T) lanes per vector):
-//   planes kl = 0 .. nzl+1   (kl = 0 and nzl+1 are ghost planes; global k = kg0 + kl)
+//   planes kl = 0 .. nzl+2G-1 (G ghost planes either side of the nzl interior planes; global k = kg0 + kl)
 //   rows   j  = 0 .. N+1
 //   row pitch px (multiple of 128 B); cell i lives at row_base + lead + (i-1), with
 //   lead*sizeof(T) = 128 B, so interior cell i = 1 starts a 128-byte line in every row and a
@@ -24,8 +24,10 @@ namespace sfk {
 
 struct Geom {
     int N;        // interior cells per axis
-    int nzl;      // interior planes held by this slab
-    int kg0;      // global k of local plane 0 (= first interior k - 1)
+    int nzl;      // interior planes held by this slab (local planes G .. G+nzl-1)
+    int G;        // ghost planes per side (1, or 2 when sweep pairs are fused across slabs)
+    int np;       // planes stored = nzl + 2G
+    int kg0;      // global k of local plane 0 (= first interior k - G)
     int px;       // row pitch, elements
     int lead;     // element offset of cell i = 1 inside a row
     long plane;   // plane stride, elements (= px * (N+2))
@@ -522,7 +524,7 @@ __global__ void __launch_bounds__(256) jacobi2_kernel(Geom g, JacobiArgs<T, NF> 
 #pragma unroll
     for (int r = 0; r < RK + 4; ++r) {
         int kl = k0 - 2 + r;
-        kl = kl < 0 ? 0 : (kl > g.nzl + 1 ? g.nzl + 1 : kl);
+        kl = kl < 0 ? 0 : (kl > g.np - 1 ? g.np - 1 : kl);
         planeq[r] = (long)kl * g.plane;
     }
     // distance of block-local coordinate a in [-2, R+1] from the output range [0, R-1]
@@ -718,7 +720,7 @@ __global__ void __launch_bounds__(512) jacobi2m_kernel(Geom g, JacobiArgs<T, NF>
         const int jc = j < 0 ? 0 : (j > N + 1 ? N + 1 : j);
         rowq[p] = (long)jc * g.px + (g.lead - 1) + i0;
     }
-    const int kmax = g.nzl + 1;
+    const int kmax = g.np - 1;
     auto planeq = [&](int kl) -> long {
         kl = kl < 0 ? 0 : (kl > kmax ? kmax : kl);
         return (long)kl * g.plane;
@@ -910,9 +912,9 @@ __global__ void __launch_bounds__(256) advect_kernel(Geom g, AdvectArgs<T, NF> A
         const T t1 = y - (T)ja, t0 = T(1) - t1;
         const T r1 = z - (T)ka, r0 = T(1) - r1;
         int kla = ka - g.kg0;  // local plane of k0; k1 = kla + 1 must also be stored
-        if (kla < 0 || kla > g.nzl) {
+        if (kla < 0 || kla > g.np - 2) {
             bad = true;
-            kla = kla < 0 ? 0 : g.nzl;
+            kla = kla < 0 ? 0 : g.np - 2;
         }
         const long p00 = row0(g, ja, kla) + ia;  // (i0,j0,k0)
         const long p01 = p00 + g.plane;          // (i0,j0,k1)
@@ -1026,7 +1028,7 @@ __global__ void __launch_bounds__(256) set_bnd_kernel(Geom g, T* __restrict__ x,
         // i- and j-faces of every local interior plane, k-faces on wall slabs.
         const long per = (long)N * g.nzl;  // (a, kl) pairs
         if (t < per) {
-            const int a = 1 + (int)(t % N), kl = 1 + (int)(t / N);
+            const int a = 1 + (int)(t % N), kl = g.G + (int)(t / N);
             at(0, a, kl) = sx * at(1, a, kl);
             at(E, a, kl) = sx * at(N, a, kl);
             at(a, 0, kl) = sy * at(a, 1, kl);
@@ -1041,7 +1043,7 @@ __global__ void __launch_bounds__(256) set_bnd_kernel(Geom g, T* __restrict__ x,
     } else if (pass == 1) {
         // z-directed edges on every local interior plane
         if (t < g.nzl) {
-            const int kl = 1 + (int)t;
+            const int kl = g.G + (int)t;
             for (int a = 0; a < 2; ++a)
                 for (int c = 0; c < 2; ++c) {
                     const int I = a ? E : 0, In = a ? N : 1, J = c ? E : 0, Jn = c ? N : 1;

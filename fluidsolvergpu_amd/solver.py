@@ -26,7 +26,7 @@ NCCL_ID_BYTES = 128
 # every symbol include/sfgpu.h declares (tests check that the library exports all of them)
 ABI_SYMBOLS = (
     "sf_version", "sf_status_string", "sf_nccl_unique_id", "sf_create", "sf_destroy", "sf_upload",
-    "sf_download", "sf_download_planes", "sf_upload_planes", "sf_owned_planes", "sf_fill", "sf_copy_field", "vel_step",
+    "sf_download", "sf_download_planes", "sf_upload_planes", "sf_owned_planes", "sf_stored_planes", "sf_fill", "sf_copy_field", "vel_step",
     "dens_step", "sf_add_source", "sf_set_bnd", "sf_lin_solve", "sf_diffuse", "sf_advect", "sf_project",
     "sf_set_iters", "sf_set_coefficients", "sf_sync", "sf_last_error", "sf_timer_start", "sf_timer_stop",
     "sf_measure_copy_bandwidth", "sf_layout_info", "sf_lin_solve_launches",
@@ -54,6 +54,7 @@ lib.sf_download.argtypes = [_ctx, C.c_int, C.c_void_p]
 lib.sf_download_planes.argtypes = [_ctx, C.c_int, C.c_int, C.c_int, C.c_void_p]
 lib.sf_upload_planes.argtypes = [_ctx, C.c_int, C.c_int, C.c_int, C.c_void_p]
 lib.sf_owned_planes.argtypes = [_ctx, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+lib.sf_stored_planes.argtypes = [_ctx, C.POINTER(C.c_int), C.POINTER(C.c_int)]
 lib.sf_fill.argtypes = [_ctx, C.c_int, C.c_double]
 lib.sf_copy_field.argtypes = [_ctx, C.c_int, C.c_int]
 lib.vel_step.argtypes = [_ctx]
@@ -166,9 +167,10 @@ class FluidSolver:
                                       a.ctypes.data_as(C.c_void_p)))
 
     def stored_planes(self):
-        """Global planes this context stores: its interior planes plus one ghost/shell plane each side."""
-        kb, ke = self.owned_planes()
-        return kb - 1, ke + 1
+        """Global planes this context stores: its interior planes plus its ghost / shell planes."""
+        kb, ke = C.c_int(), C.c_int()
+        self._ck(lib.sf_stored_planes(self._h, C.byref(kb), C.byref(ke)))
+        return kb.value, ke.value
 
     def owned_planes(self):
         kb, ke = C.c_int(), C.c_int()

@@ -90,6 +90,9 @@ int sf_upload_planes(sf_ctx* ctx, int field, int k_begin, int k_end, const void*
  * accepts any [k_begin, k_end) and copies the planes of it that this context STORES (its interior
  * planes and the ghost / shell plane either side), so a rank can upload just its own part. */
 int sf_owned_planes(const sf_ctx* ctx, int* k_begin, int* k_end);
+/* Global planes [k_begin, k_end) this context stores (owned planes plus its ghost / shell planes, clipped
+ * to 0 .. N+2): the range a rank should fill with sf_upload_planes before the first step. */
+int sf_stored_planes(const sf_ctx* ctx, int* k_begin, int* k_end);
 
 /* Device-side helpers, asynchronous. */
 int sf_fill(sf_ctx* ctx, int field, double value);        /* every stored entry = value           */

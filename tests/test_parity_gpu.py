@@ -192,6 +192,55 @@ def test_slabs_full_step_bit_identical(N, P, dtype):
         assert_same(got[n], f[n], f"P={P}: {n}")
 
 
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "f64"])
+@pytest.mark.parametrize("N,P,K,steps", [(64, 2, 7, 2), (64, 8, 6, 1), (48, 4, 4, 2), (128, 4, 5, 1)])
+def test_slabs_fused_pairs_two_ghost_planes(N, P, K, steps, dtype):
+    """N % vector width == 0 and >= 2 planes per slab: sweep pairs are fused across slab boundaries (two ghost
+    planes, one exchange per pair, div recomputed on the first ghost plane). Must still equal the oracle."""
+    f = small_velocity(rand_fields(N, dtype, 21), N, dtype)
+    src = {n: f[n].copy() for n in ("u0", "v0", "w0", "dens0")}
+    with make(N, dtype, K=K, nslabs_local=P) as fs:
+        for n in NAMES:
+            fs.upload(n, f[n])
+        for s in range(steps):
+            if s > 0:
+                for n in src:
+                    fs.upload(n, src[n])
+            fs.vel_step()
+            fs.dens_step()
+        fs.sync()
+        got = {n: fs.download(n) for n in NAMES}
+    for s in range(steps):
+        if s > 0:
+            for n in src:
+                f[n][...] = src[n]
+        O.step(N, f, dtype(DT), dtype(DIFF), dtype(VISC), K)
+    for n in NAMES:
+        assert_same(got[n], f[n], f"P={P} fused: {n}")
+
+
+def test_upload_planes_fills_all_ghosts():
+    """A rank that fills exactly sf_stored_planes() with sf_upload_planes gets the same state as sf_upload."""
+    N, dtype, P = 16, np.float32, 4
+    f = small_velocity(rand_fields(N, dtype, 22), N, dtype)
+    out = []
+    for mode in ("full", "planes"):
+        with make(N, dtype, K=4, nslabs_local=P) as fs:
+            kb, ke = fs.stored_planes()
+            assert (kb, ke) == (0, N + 2)
+            for n in NAMES:
+                if mode == "full":
+                    fs.upload(n, f[n])
+                else:
+                    fs.upload_planes(n, kb, f[n][kb:ke])
+            fs.vel_step()
+            fs.dens_step()
+            fs.sync()
+            out.append({n: fs.download(n) for n in NAMES})
+    for n in NAMES:
+        assert_same(out[1][n], out[0][n], n)
+
+
 @pytest.mark.parametrize("P", [2, 4])
 def test_slabs_each_operator(P):
     N, dtype, K = 16, np.float32, 4
