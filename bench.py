@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--roofline-n", type=int, default=512, help="also time the lin_solve sweep at this size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--local-slabs", type=int, default=1,
+                    help="rehearsal: cut this rank's part into that many logical slabs on its one GPU")
     return ap.parse_args()
 
 
@@ -148,7 +150,7 @@ def main():
     assert N % world == 0, f"grid {N} not divisible by {world} ranks"
     nccl_id = sfdist.share_nccl_id(dist, S.nccl_unique_id)
     fs = S.FluidSolver(N, dtype=args.dtype, iters=K, dt=dt, diff=diff, visc=visc, device=local_rank, rank=rank,
-                       nranks=world, nccl_id=nccl_id)
+                       nranks=world, nccl_id=nccl_id, nslabs_local=args.local_slabs)
     kb, ke = fs.stored_planes()
     f = analytic_planes(N, kb, ke, dt, fs.np_dtype)
     for name, slot in (("u", "u"), ("v", "v"), ("w", "w"), ("dens", "dens"), ("su", "user0"), ("sv", "user1"),
@@ -211,7 +213,7 @@ def main():
             "data": "synthetic (analytic fields of docs/SPEC.md §5, resident in HBM)",
             "config": {"workload": f"{N}^3 {args.dtype}, K={K} Jacobi iters per lin_solve, vel_step+dens_step "
                                    f"with per-step source re-injection", "grid": N, "jacobi_iters": K,
-                       "slabs": world, "cells_per_gpu": cells / world,
+                       "slabs": world * args.local_slabs, "cells_per_gpu": cells / world,
                        "parallelism": f"k-slab x{world}" + (" (RCCL halo exchange)" if world > 1 else "")},
             "achieved_hbm_gbps_step": step_bytes / (elapsed / args.steps) / 1e9 / world,
             "step_algorithmic_bytes_per_cell": words_per_cell_step(K) * wsize,

@@ -91,6 +91,11 @@ public:
     virtual double copy_bandwidth(size_t bytes, int reps) = 0;
     virtual void layout_info(int* pitch, int* planes, size_t* bytes) const = 0;
     virtual int lin_solve_launches(int iters) const = 0;
+    virtual void snapshot(const int* fields, int nfields) = 0;
+    virtual void snapshot_read(int index, void* host) = 0;
+    virtual void tracers_set(int n, const void* xyz) = 0;
+    virtual void tracers_advect() = 0;
+    virtual void tracers_get(void* xyz, void* dens, void* speed) = 0;
 };
 
 template <class T>
@@ -103,6 +108,9 @@ class Solver final : public SolverBase {
         sfk::Geom geom{};
         T* field[SF_NUM_FIELDS] = {};
         T* scratch[NSCRATCH] = {};
+        T* snap[4] = {};               // snapshot buffers for asynchronous output
+        hipStream_t os = nullptr;      // output (copy) stream
+        hipEvent_t snap_done = nullptr;
         hipStream_t cs = nullptr;  // compute
         hipStream_t hs = nullptr;  // halo
         hipEvent_t boundary_done = nullptr;
@@ -188,6 +196,7 @@ public:
         // but with one 512-thread workgroup per CU it is latency-bound — 305 vs 267 us/sweep at 512^3)
         fuse2_ = env_int("SF_FUSE2", 1);
         kc2_ = env_int("SF_KC2", 32);
+        f2_shape_ = env_int("SF_F2", 22);
         tx_override_ = env_int("SF_TX", 0);
         SF_HIP(hipDeviceSynchronize());
     }
@@ -202,6 +211,10 @@ public:
             for (T*& f : sl.scratch)
                 if (f) (void)hipFree(f);
             if (sl.d_flag) (void)hipFree(sl.d_flag);
+            for (T*& f : sl.snap)
+                if (f) (void)hipFree(f);
+            if (sl.os) (void)hipStreamDestroy(sl.os);
+            if (sl.snap_done) (void)hipEventDestroy(sl.snap_done);
             if (sl.cs) (void)hipStreamDestroy(sl.cs);
             if (sl.hs) (void)hipStreamDestroy(sl.hs);
             if (sl.boundary_done) (void)hipEventDestroy(sl.boundary_done);
@@ -209,6 +222,9 @@ public:
         }
         if (t0_) (void)hipEventDestroy(t0_);
         if (t1_) (void)hipEventDestroy(t1_);
+        if (tr_pos_) (void)hipFree(tr_pos_);
+        if (tr_dens_) (void)hipFree(tr_dens_);
+        if (tr_speed_) (void)hipFree(tr_speed_);
         if (copy_src_) (void)hipFree(copy_src_);
         if (copy_dst_) (void)hipFree(copy_dst_);
     }
@@ -473,7 +489,10 @@ public:
         SF_HIP(hipSetDevice(device_));
         bytes = (bytes + 4095) / 4096 * 4096;
         if (copy_bytes_ != bytes) {
-            if (copy_src_) (void)hipFree(copy_src_);
+            if (tr_pos_) (void)hipFree(tr_pos_);
+        if (tr_dens_) (void)hipFree(tr_dens_);
+        if (tr_speed_) (void)hipFree(tr_speed_);
+        if (copy_src_) (void)hipFree(copy_src_);
             if (copy_dst_) (void)hipFree(copy_dst_);
             copy_src_ = copy_dst_ = nullptr;
             SF_HIP(hipMalloc(&copy_src_, bytes));
@@ -497,6 +516,85 @@ public:
             if (r > 0 && ms < best_ms) best_ms = ms;
         }
         return 2.0 * (double)bytes / (best_ms * 1e-3) / 1e9;
+    }
+
+    // ---- asynchronous output -----------------------------------------------------------------
+    void snapshot(const int* fields, int nfields) override {
+        SF_REQUIRE(fields != nullptr && nfields >= 1 && nfields <= 4, "snapshot takes 1..4 fields");
+        SF_HIP(hipSetDevice(device_));
+        for (int q = 0; q < nfields; ++q) check_field(fields[q]);
+        for (Slab& sl : slabs_) {
+            if (!sl.os) SF_HIP(hipStreamCreateWithFlags(&sl.os, hipStreamNonBlocking));
+            if (!sl.snap_done) SF_HIP(hipEventCreateWithFlags(&sl.snap_done, hipEventDisableTiming));
+            for (int q = 0; q < nfields; ++q) {
+                if (!sl.snap[q]) sl.snap[q] = alloc_field();
+                SF_HIP(hipMemcpyAsync(sl.snap[q], ensure(sl, fields[q]), (size_t)field_elems_ * sizeof(T),
+                                      hipMemcpyDeviceToDevice, sl.cs));
+            }
+            SF_HIP(hipEventRecord(sl.snap_done, sl.cs));
+        }
+        snap_count_ = nfields;
+    }
+
+    // May run on another host thread: touches only the snapshot buffers, the output stream and snap_done.
+    void snapshot_read(int index, void* host) override {
+        SF_REQUIRE(index >= 0 && index < snap_count_, "snapshot index out of range");
+        SF_REQUIRE(host != nullptr, "null host pointer");
+        SF_HIP(hipSetDevice(device_));
+        const size_t S = (size_t)N_ + 2;
+        for (Slab& sl : slabs_) {
+            SF_HIP(hipStreamWaitEvent(sl.os, sl.snap_done, 0));
+            const int kb = sl.geom.kg0 + G_ - (sl.geom.wall_lo ? 1 : 0);
+            const int ke = sl.geom.kg0 + G_ + nzl_ + (sl.geom.wall_hi ? 1 : 0);
+            SF_HIP(hipMemcpy2DAsync(static_cast<T*>(host) + (size_t)kb * S * S, S * sizeof(T),
+                                    sl.snap[index] + (size_t)(kb - sl.geom.kg0) * plane_ + (lead_ - 1),
+                                    (size_t)px_ * sizeof(T), S * sizeof(T), S * (size_t)(ke - kb),
+                                    hipMemcpyDeviceToHost, sl.os));
+        }
+        for (Slab& sl : slabs_) SF_HIP(hipStreamSynchronize(sl.os));
+    }
+
+    // ---- tracers (SPEC §6) ----------------------------------------------------------------------
+    void tracers_set(int n, const void* xyz) override {
+        SF_REQUIRE(P_ == 1, "tracers need a single-slab context");
+        SF_REQUIRE(n >= 0 && (n == 0 || xyz != nullptr), "bad tracer array");
+        SF_HIP(hipSetDevice(device_));
+        if (tr_pos_) (void)hipFree(tr_pos_);
+        if (tr_dens_) (void)hipFree(tr_dens_);
+        if (tr_speed_) (void)hipFree(tr_speed_);
+        tr_pos_ = tr_dens_ = tr_speed_ = nullptr;
+        tr_n_ = n;
+        if (n == 0) return;
+        SF_HIP(hipMalloc(&tr_pos_, (size_t)3 * n * sizeof(T)));
+        SF_HIP(hipMalloc(&tr_dens_, (size_t)n * sizeof(T)));
+        SF_HIP(hipMalloc(&tr_speed_, (size_t)n * sizeof(T)));
+        SF_HIP(hipMemcpyAsync(tr_pos_, xyz, (size_t)3 * n * sizeof(T), hipMemcpyHostToDevice, slabs_[0].cs));
+        SF_HIP(hipStreamSynchronize(slabs_[0].cs));
+    }
+    void tracers_advect() override {
+        SF_REQUIRE(P_ == 1, "tracers need a single-slab context");
+        if (tr_n_ == 0) return;
+        SF_HIP(hipSetDevice(device_));
+        Slab& sl = slabs_[0];
+        hipLaunchKernelGGL((sfk::tracers_advect_kernel<T>), dim3((unsigned)ceil_div(tr_n_, 256)), dim3(256), 0, sl.cs,
+                           sl.geom, tr_n_, tr_pos_, sl.field[SF_U], sl.field[SF_V], sl.field[SF_W], dt_ * (T)N_);
+        SF_HIP(hipGetLastError());
+    }
+    void tracers_get(void* xyz, void* dens, void* speed) override {
+        SF_REQUIRE(P_ == 1, "tracers need a single-slab context");
+        if (tr_n_ == 0) return;
+        SF_HIP(hipSetDevice(device_));
+        Slab& sl = slabs_[0];
+        if (dens || speed) {
+            hipLaunchKernelGGL((sfk::tracers_sample_kernel<T>), dim3((unsigned)ceil_div(tr_n_, 256)), dim3(256), 0,
+                               sl.cs, sl.geom, tr_n_, tr_pos_, sl.field[SF_DENS], sl.field[SF_U], sl.field[SF_V],
+                               sl.field[SF_W], tr_dens_, tr_speed_);
+            SF_HIP(hipGetLastError());
+        }
+        if (xyz) SF_HIP(hipMemcpyAsync(xyz, tr_pos_, (size_t)3 * tr_n_ * sizeof(T), hipMemcpyDeviceToHost, sl.cs));
+        if (dens) SF_HIP(hipMemcpyAsync(dens, tr_dens_, (size_t)tr_n_ * sizeof(T), hipMemcpyDeviceToHost, sl.cs));
+        if (speed) SF_HIP(hipMemcpyAsync(speed, tr_speed_, (size_t)tr_n_ * sizeof(T), hipMemcpyDeviceToHost, sl.cs));
+        SF_HIP(hipStreamSynchronize(sl.cs));
     }
 
     int lin_solve_launches(int iters) const override { return can_fuse2() ? iters / 2 + iters % 2 : iters; }
@@ -817,9 +915,20 @@ private:
             return;
         }
         if (nt)
-            launch_fused2<NF, true, 2, 2>(sl, A, kb, ke, first, last);
+            launch_fused2_shape<NF, true>(sl, A, kb, ke, first, last);
         else
-            launch_fused2<NF, false, 2, 2>(sl, A, kb, ke, first, last);
+            launch_fused2_shape<NF, false>(sl, A, kb, ke, first, last);
+    }
+
+    template <int NF, bool NT>
+    void launch_fused2_shape(Slab& sl, const sfk::JacobiArgs<T, NF>& A, int kb, int ke, bool first, bool last) {
+        switch (f2_shape_) {
+            case 21: launch_fused2<NF, NT, 2, 1>(sl, A, kb, ke, first, last); break;
+            case 12: launch_fused2<NF, NT, 1, 2>(sl, A, kb, ke, first, last); break;
+            case 11: launch_fused2<NF, NT, 1, 1>(sl, A, kb, ke, first, last); break;
+            case 42: launch_fused2<NF, NT, 4, 2>(sl, A, kb, ke, first, last); break;
+            default: launch_fused2<NF, NT, 2, 2>(sl, A, kb, ke, first, last); break;
+        }
     }
 
     // K Jacobi sweeps on NF fields at once; scratch buffers are swapped into the slots.
@@ -941,11 +1050,15 @@ private:
     int num_cu_ = 256;
     int nzl_ = 0, lead_ = 0, px_ = 0, nplanes_ = 0, kchunk_ = 0, jacobi_mode_ = 2, tx_override_ = 0, nt_mode_ = 2, rb_shape_ = 0;
     bool ishell_skip_ = true;
-    int fuse2_ = 1, kc2_ = 32;
+    int fuse2_ = 1, kc2_ = 32, f2_shape_ = 22;
     long plane_ = 0, field_elems_ = 0;
     std::vector<Slab> slabs_;
     ncclComm_t comm_ = nullptr;
     hipEvent_t t0_ = nullptr, t1_ = nullptr;
+    T* tr_pos_ = nullptr;
+    T* tr_dens_ = nullptr;
+    T* tr_speed_ = nullptr;
+    int tr_n_ = 0, snap_count_ = 0;
     void* copy_src_ = nullptr;
     void* copy_dst_ = nullptr;
     size_t copy_bytes_ = 0;
@@ -956,6 +1069,7 @@ private:
 struct sf_ctx {
     std::unique_ptr<SolverBase> impl;
     std::string err;
+    std::string snap_err;  // sf_snapshot_read may run on another thread: it gets its own message buffer
 };
 
 namespace {
@@ -1081,6 +1195,28 @@ int sf_advect(sf_ctx* ctx, int b, int d, int d0, int u, int v, int w) {
 }
 int sf_project(sf_ctx* ctx, int u, int v, int w, int p, int div) {
     return guarded(ctx, [&](SolverBase& s) { s.project(u, v, w, p, div); });
+}
+int sf_snapshot(sf_ctx* ctx, const int* fields, int nfields) {
+    return guarded(ctx, [&](SolverBase& s) { s.snapshot(fields, nfields); });
+}
+int sf_snapshot_read(sf_ctx* ctx, int index, void* host) {
+    if (!ctx || !ctx->impl) return SF_ERR_INVALID;
+    try {
+        ctx->impl->snapshot_read(index, host);
+        return SF_OK;
+    } catch (const Failure& f) {
+        ctx->snap_err = f.msg;
+        return f.code;
+    }
+}
+int sf_tracers_set(sf_ctx* ctx, int n, const void* xyz) {
+    return guarded(ctx, [&](SolverBase& s) { s.tracers_set(n, xyz); });
+}
+int sf_tracers_advect(sf_ctx* ctx) {
+    return guarded(ctx, [&](SolverBase& s) { s.tracers_advect(); });
+}
+int sf_tracers_get(sf_ctx* ctx, void* xyz, void* dens_sample, void* speed_sample) {
+    return guarded(ctx, [&](SolverBase& s) { s.tracers_get(xyz, dens_sample, speed_sample); });
 }
 int sf_set_iters(sf_ctx* ctx, int iters) {
     return guarded(ctx, [&](SolverBase& s) { s.set_iters(iters); });

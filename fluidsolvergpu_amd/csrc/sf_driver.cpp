@@ -9,8 +9,15 @@
 // run-time option, and the grid solver behind vel_step/dens_step is the stable-fluids path of
 // docs/SPEC.md, not the reference's SPH kernels.
 //
+// Output is asynchronous: at an output step the fields are snapshotted on the device and a
+// writer thread downloads and encodes the frame while the main loop keeps stepping; the reference blocks on
+// cudaDeviceSynchronize + cudaMemcpy + per-value sprintf instead (solver-unidyn.cu:475-487). With --tracers N a
+// cloud of passive tracers is advected through the velocity field and written with write_point_mesh, the one
+// writer call the reference really makes (solver-unidyn.cu:487: ASCII, two point scalars).
+//
 //   sf_driver [--n 64] [--steps 20] [--iters 20] [--dtype f32|f64] [--every 10] [--out DIR]
-//             [--binary] [--device 0] [--slabs 1] [--plumbing] [--quiet]
+//             [--binary] [--device 0] [--slabs 1] [--plumbing] [--quiet] [--sync-output] [--tracers 0]
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -18,6 +25,7 @@
 #include <iostream>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/sf_visit_writer.h"
@@ -36,8 +44,8 @@ static sf_ctx* g_ctx = nullptr;
     }
 
 struct Options {
-    int n = 64, steps = 20, iters = 20, every = 10, device = 0, slabs = 1;
-    bool f64 = false, binary = false, plumbing = false, quiet = false;
+    int n = 64, steps = 20, iters = 20, every = 10, device = 0, slabs = 1, tracers = 0;
+    bool f64 = false, binary = false, plumbing = false, quiet = false, sync_output = false;
     std::string out = ".";
 };
 
@@ -63,6 +71,8 @@ static Options parse(int argc, char** argv) {
         else if (s == "--binary") o.binary = true;
         else if (s == "--plumbing") o.plumbing = true;
         else if (s == "--quiet") o.quiet = true;
+        else if (s == "--sync-output") o.sync_output = true;
+        else if (s == "--tracers") o.tracers = atoi(next());
         else {
             fprintf(stderr, "unknown option %s\n", s.c_str());
             exit(2);
@@ -167,7 +177,43 @@ static int run(const Options& o) {
 
     const size_t n = ((size_t)o.n + 2) * ((size_t)o.n + 2) * ((size_t)o.n + 2);
     std::vector<T> hd(n), hu(n), hv(n), hw(n);
+
+    // tracers: a small lattice in the middle of the box, in grid-index coordinates (SPEC §6)
+    std::vector<T> tpos, tdens, tspeed;
+    if (o.tracers > 0 && o.slabs == 1) {
+        int side = 1;
+        while (side * side * side < o.tracers) ++side;
+        for (int c = 0; c < side && (int)tpos.size() / 3 < o.tracers; ++c)
+            for (int b = 0; b < side && (int)tpos.size() / 3 < o.tracers; ++b)
+                for (int a = 0; a < side && (int)tpos.size() / 3 < o.tracers; ++a) {
+                    tpos.push_back((T)(0.25 * o.n + 0.5 * o.n * (a + 0.5) / side));
+                    tpos.push_back((T)(0.25 * o.n + 0.5 * o.n * (b + 0.5) / side));
+                    tpos.push_back((T)(0.25 * o.n + 0.5 * o.n * (c + 0.5) / side));
+                }
+        tdens.resize(tpos.size() / 3);
+        tspeed.resize(tpos.size() / 3);
+        SF_CHECK_RETURN(sf_tracers_set(g_ctx, (int)(tpos.size() / 3), tpos.data()));
+    }
+    const int ntr = (int)(tpos.size() / 3);
+
+    std::thread writer;  // at most one frame in flight
+    auto write_tracers = [&](int frame) {
+        std::vector<float> pts(3 * (size_t)ntr), m(ntr), sp(ntr);
+        for (int q = 0; q < 3 * ntr; ++q) pts[q] = (float)tpos[q];
+        for (int q = 0; q < ntr; ++q) {
+            m[q] = (float)tdens[q];
+            sp[q] = (float)tspeed[q];
+        }
+        std::ostringstream oss;
+        oss << o.out << "/tracers_s" << frame << ".vtk";
+        int vardims[2] = {1, 1};
+        const char* names[2] = {"density", "speed"};
+        float* arrays[2] = {m.data(), sp.data()};
+        write_point_mesh(oss.str().c_str(), 0, ntr, pts.data(), 2, vardims, names, arrays);  // solver-unidyn.cu:487
+    };
+
     double total_ms = 0;
+    const auto wall0 = std::chrono::steady_clock::now();
     for (int t = 0; t < o.steps; t++) {
         if (!o.quiet) std::cout << "t= " << t << "\n";
         float elapsedTime = 0.f;
@@ -178,19 +224,44 @@ static int run(const Options& o) {
         SF_CHECK_RETURN(sf_copy_field(g_ctx, SF_DENS0, SF_USER3));
         SF_CHECK_RETURN(vel_step(g_ctx));
         SF_CHECK_RETURN(dens_step(g_ctx));
+        if (ntr > 0) SF_CHECK_RETURN(sf_tracers_advect(g_ctx));
         SF_CHECK_RETURN(sf_timer_stop(g_ctx, &elapsedTime));
-        SF_CHECK_RETURN(sf_sync(g_ctx));
         total_ms += elapsedTime;
         if (!o.quiet) std::cout << "done.\nElapsed kernel time: " << elapsedTime << " ms\n";
 
         if (o.every > 0 && t % o.every == 0) {
-            SF_CHECK_RETURN(sf_download(g_ctx, SF_DENS, hd.data()));
-            SF_CHECK_RETURN(sf_download(g_ctx, SF_U, hu.data()));
-            SF_CHECK_RETURN(sf_download(g_ctx, SF_V, hv.data()));
-            SF_CHECK_RETURN(sf_download(g_ctx, SF_W, hw.data()));
-            write_frame<T>(o, t / o.every, hd, hu, hv, hw);
+            const int frame = t / o.every;
+            if (writer.joinable()) writer.join();  // the previous frame must be out before its buffers are reused
+            if (ntr > 0) SF_CHECK_RETURN(sf_tracers_get(g_ctx, tpos.data(), tdens.data(), tspeed.data()));
+            if (o.sync_output) {
+                SF_CHECK_RETURN(sf_sync(g_ctx));
+                SF_CHECK_RETURN(sf_download(g_ctx, SF_DENS, hd.data()));
+                SF_CHECK_RETURN(sf_download(g_ctx, SF_U, hu.data()));
+                SF_CHECK_RETURN(sf_download(g_ctx, SF_V, hv.data()));
+                SF_CHECK_RETURN(sf_download(g_ctx, SF_W, hw.data()));
+                write_frame<T>(o, frame, hd, hu, hv, hw);
+                if (ntr > 0) write_tracers(frame);
+            } else {
+                const int fields[4] = {SF_DENS, SF_U, SF_V, SF_W};
+                SF_CHECK_RETURN(sf_snapshot(g_ctx, fields, 4));
+                writer = std::thread([&, frame]() {
+                    T* dst[4] = {hd.data(), hu.data(), hv.data(), hw.data()};
+                    for (int q = 0; q < 4; ++q)
+                        if (sf_snapshot_read(g_ctx, q, dst[q]) != SF_OK) {
+                            fprintf(stderr, "Error: snapshot read failed for frame %d\n", frame);
+                            exit(1);
+                        }
+                    write_frame<T>(o, frame, hd, hu, hv, hw);
+                    if (ntr > 0) write_tracers(frame);
+                });
+            }
         }
     }
+    if (writer.joinable()) writer.join();
+    SF_CHECK_RETURN(sf_sync(g_ctx));
+    const double wall_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count();
+    std::cout << "wall time of the loop incl. output: " << wall_s << " s ("
+              << (o.sync_output ? "synchronous" : "asynchronous") << " output)\n";
     const double cells = (double)o.n * o.n * o.n;
     if (o.steps > 0)
         std::cout << "mean step " << total_ms / o.steps << " ms, " << cells * o.steps / (total_ms * 1e-3) / 1e6

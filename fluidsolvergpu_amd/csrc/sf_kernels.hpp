@@ -459,8 +459,11 @@ __global__ void __launch_bounds__(256) jacobi_rb_kernel(Geom g, JacobiArgs<T, NF
 // sweeps. A workgroup spans whole rows (blockDim.x = ceil(N/W) rounded up to 64); the only values that
 // cross waves are the end cells of y, exchanged through a few words of LDS.
 // Requirements (checked by the launcher): N % W == 0, ceil(N/W) <= 256, one slab (P = 1).
+#ifndef SF_J2_WAVES
+#define SF_J2_WAVES 2
+#endif
 template <class T, int NF, bool NT, int RJ, int RK>
-__global__ void __launch_bounds__(256) jacobi2_kernel(Geom g, JacobiArgs<T, NF> A, int kb, int ke,
+__global__ void __launch_bounds__(256, SF_J2_WAVES) jacobi2_kernel(Geom g, JacobiArgs<T, NF> A, int kb, int ke,
                                                        TileMap m) {
     constexpr int W = VecT<T>::W;
     typedef typename VecT<T>::type V;
@@ -1074,6 +1077,79 @@ __global__ void __launch_bounds__(256) set_bnd_kernel(Geom g, T* __restrict__ x,
             }
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Tracer particles (docs/SPEC.md §6): the trilinear sample of advect applied at arbitrary points.
+template <class T>
+struct TriSampleDev {
+    long q;
+    long dj, dk;
+    T s0, s1, t0, t1, r0, r1;
+    __device__ TriSampleDev(const Geom& g, T x, T y, T z) {
+        const int N = g.N;
+        const T Nf = (T)N, lo = T(0.5), hi = Nf + T(0.5);
+        if (x < lo) x = lo;
+        if (x > hi) x = hi;
+        if (y < lo) y = lo;
+        if (y > hi) y = hi;
+        if (z < lo) z = lo;
+        if (z > hi) z = hi;
+        int i0 = (x == x) ? (int)x : 0, j0 = (y == y) ? (int)y : 0, k0 = (z == z) ? (int)z : 0;
+        i0 = i0 < 0 ? 0 : (i0 > N ? N : i0);
+        j0 = j0 < 0 ? 0 : (j0 > N ? N : j0);
+        k0 = k0 < 0 ? 0 : (k0 > N ? N : k0);
+        s1 = x - (T)i0;
+        s0 = T(1) - s1;
+        t1 = y - (T)j0;
+        t0 = T(1) - t1;
+        r1 = z - (T)k0;
+        r0 = T(1) - r1;
+        q = row0(g, j0, k0 - g.kg0) + i0;
+        dj = g.px;
+        dk = g.plane;
+    }
+    __device__ T operator()(const T* __restrict__ d0) const {
+        return s0 * (t0 * (r0 * d0[q] + r1 * d0[q + dk]) + t1 * (r0 * d0[q + dj] + r1 * d0[q + dj + dk])) +
+               s1 * (t0 * (r0 * d0[q + 1] + r1 * d0[q + 1 + dk]) +
+                     t1 * (r0 * d0[q + 1 + dj] + r1 * d0[q + 1 + dj + dk]));
+    }
+};
+
+template <class T>
+__device__ __forceinline__ T clamp_coord(int N, T x) {
+    const T lo = T(0.5), hi = (T)N + T(0.5);
+    if (x < lo) x = lo;
+    if (x > hi) x = hi;
+    return x;
+}
+
+template <class T>
+__global__ void __launch_bounds__(256) tracers_advect_kernel(Geom g, int n, T* __restrict__ pos,
+                                                              const T* __restrict__ u, const T* __restrict__ v,
+                                                              const T* __restrict__ w, T dt0) {
+    const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (t >= n) return;
+    const int N = g.N;
+    const T x = clamp_coord(N, pos[3 * t]), y = clamp_coord(N, pos[3 * t + 1]), z = clamp_coord(N, pos[3 * t + 2]);
+    const TriSampleDev<T> S(g, x, y, z);
+    const T vx = S(u), vy = S(v), vz = S(w);
+    pos[3 * t] = clamp_coord(N, x + dt0 * vx);
+    pos[3 * t + 1] = clamp_coord(N, y + dt0 * vy);
+    pos[3 * t + 2] = clamp_coord(N, z + dt0 * vz);
+}
+
+template <class T>
+__global__ void __launch_bounds__(256) tracers_sample_kernel(Geom g, int n, const T* __restrict__ pos,
+                                                              const T* __restrict__ dens, const T* __restrict__ u,
+                                                              const T* __restrict__ v, const T* __restrict__ w,
+                                                              T* __restrict__ dens_out, T* __restrict__ speed_out) {
+    const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (t >= n) return;
+    const TriSampleDev<T> S(g, pos[3 * t], pos[3 * t + 1], pos[3 * t + 2]);
+    const T a = S(u), b = S(v), c = S(w);
+    dens_out[t] = S(dens);
+    speed_out[t] = sqrt((a * a + b * b) + c * c);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsfgpu.so")
+LIB_PATH = os.path.join(_HERE, os.environ.get("SF_LIB", "libsfgpu.so"))  # SF_LIB: experimental builds
 if not os.path.exists(LIB_PATH):
     raise ImportError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
 lib = C.CDLL(LIB_PATH)
@@ -29,7 +29,8 @@ ABI_SYMBOLS = (
     "sf_download", "sf_download_planes", "sf_upload_planes", "sf_owned_planes", "sf_stored_planes", "sf_fill", "sf_copy_field", "vel_step",
     "dens_step", "sf_add_source", "sf_set_bnd", "sf_lin_solve", "sf_diffuse", "sf_advect", "sf_project",
     "sf_set_iters", "sf_set_coefficients", "sf_sync", "sf_last_error", "sf_timer_start", "sf_timer_stop",
-    "sf_measure_copy_bandwidth", "sf_layout_info", "sf_lin_solve_launches",
+    "sf_measure_copy_bandwidth", "sf_layout_info", "sf_lin_solve_launches", "sf_snapshot", "sf_snapshot_read",
+    "sf_tracers_set", "sf_tracers_advect", "sf_tracers_get",
 )
 
 
@@ -72,6 +73,11 @@ lib.sf_timer_start.argtypes = [_ctx]
 lib.sf_timer_stop.argtypes = [_ctx, C.POINTER(C.c_float)]
 lib.sf_measure_copy_bandwidth.argtypes = [_ctx, C.c_size_t, C.c_int, C.POINTER(C.c_double)]
 lib.sf_lin_solve_launches.argtypes = [_ctx, C.c_int]
+lib.sf_snapshot.argtypes = [_ctx, C.POINTER(C.c_int), C.c_int]
+lib.sf_snapshot_read.argtypes = [_ctx, C.c_int, C.c_void_p]
+lib.sf_tracers_set.argtypes = [_ctx, C.c_int, C.c_void_p]
+lib.sf_tracers_advect.argtypes = [_ctx]
+lib.sf_tracers_get.argtypes = [_ctx, C.c_void_p, C.c_void_p, C.c_void_p]
 lib.sf_layout_info.argtypes = [_ctx, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_size_t)]
 
 
@@ -230,6 +236,37 @@ class FluidSolver:
         g = C.c_double()
         self._ck(lib.sf_measure_copy_bandwidth(self._h, int(nbytes), int(reps), C.byref(g)))
         return g.value
+
+    # -- asynchronous output / tracers ------------------------------------------------------
+    def snapshot(self, fields):
+        ids = (C.c_int * len(fields))(*[_fid(f) for f in fields])
+        self._ck(lib.sf_snapshot(self._h, ids, len(fields)))
+
+    def snapshot_read(self, index, out=None):
+        if out is None:
+            out = np.zeros(self.shape, self.np_dtype)
+        rc = lib.sf_snapshot_read(self._h, int(index), out.ctypes.data_as(C.c_void_p))
+        if rc != SF_OK:
+            raise SfError(rc, "sf_snapshot_read failed")
+        return out
+
+    def tracers_set(self, xyz):
+        a = np.ascontiguousarray(xyz, dtype=self.np_dtype).reshape(-1, 3)
+        self._ntr = a.shape[0]
+        self._ck(lib.sf_tracers_set(self._h, self._ntr, a.ctypes.data_as(C.c_void_p)))
+
+    def tracers_advect(self):
+        self._ck(lib.sf_tracers_advect(self._h))
+
+    def tracers_get(self, sample=True):
+        n = getattr(self, "_ntr", 0)
+        xyz = np.zeros((n, 3), self.np_dtype)
+        dens = np.zeros(n, self.np_dtype)
+        speed = np.zeros(n, self.np_dtype)
+        self._ck(lib.sf_tracers_get(self._h, xyz.ctypes.data_as(C.c_void_p),
+                                    dens.ctypes.data_as(C.c_void_p) if sample else None,
+                                    speed.ctypes.data_as(C.c_void_p) if sample else None))
+        return xyz, dens, speed
 
     def lin_solve_launches(self, iters):
         return int(lib.sf_lin_solve_launches(self._h, int(iters)))

@@ -113,6 +113,23 @@ int sf_diffuse(sf_ctx* ctx, int b, int x, int x0, double diff);
 int sf_advect(sf_ctx* ctx, int b, int d, int d0, int u, int v, int w);
 int sf_project(sf_ctx* ctx, int u, int v, int w, int p, int div);
 
+/* Asynchronous frame output (the reference blocks on cudaDeviceSynchronize + cudaMemcpy +
+ * per-value sprintf every output step, solver-unidyn.cu:475-487). sf_snapshot copies up to 4 fields into
+ * context-owned snapshot buffers on the compute stream (device to device, ordered after everything issued
+ * so far) and returns at once. sf_snapshot_read(index, host) waits for that copy only, then downloads snapshot
+ * `index` as a dense global (N+2)^3 array on a separate copy stream. It may be called from ANOTHER host
+ * thread while the owner keeps stepping; do not call sf_snapshot again before all reads have returned. */
+int sf_snapshot(sf_ctx* ctx, const int* fields, int nfields);
+int sf_snapshot_read(sf_ctx* ctx, int index, void* host);
+
+/* Tracer particles (docs/SPEC.md §6; feeds the write_point_mesh call of solver-unidyn.cu:487). Positions are
+ * x y z triples in grid-index coordinates, element type = the context's dtype. Single-slab contexts only.
+ * sf_tracers_advect moves them through SF_U/V/W by one dt; sf_tracers_get returns positions and, if the
+ * pointers are non-NULL, the density and speed sampled at each tracer. */
+int sf_tracers_set(sf_ctx* ctx, int n, const void* xyz);
+int sf_tracers_advect(sf_ctx* ctx);
+int sf_tracers_get(sf_ctx* ctx, void* xyz, void* dens_sample, void* speed_sample);
+
 /* Run-time parameters (the reference only has compile-time #defines, FluidGPU.cuh:1-31). */
 int sf_set_iters(sf_ctx* ctx, int iters);
 int sf_set_coefficients(sf_ctx* ctx, double dt, double diff, double visc);

@@ -39,6 +39,13 @@ using namespace sf_oracle;
                                            int K) {                                                 \
         dens_step<T>(N, x, x0, u, v, w, diff, dt, K);                                               \
     }                                                                                               \
+    extern "C" void oracle_tracers_advect_##SFX(int N, int n, T* pos, const T* u, const T* v, const T* w, T dt) { \
+        tracers_advect<T>(N, n, pos, u, v, w, dt);                                                  \
+    }                                                                                               \
+    extern "C" void oracle_tracers_sample_##SFX(int N, int n, const T* pos, const T* dens, const T* u,  \
+                                                const T* v, const T* w, T* dout, T* sout) {         \
+        tracers_sample<T>(N, n, pos, dens, u, v, w, dout, sout);                                    \
+    }                                                                                               \
     extern "C" void oracle_vel_step_##SFX(int N, T* u, T* v, T* w, T* u0, T* v0, T* w0, T visc,     \
                                           T dt, int K) {                                            \
         vel_step<T>(N, u, v, w, u0, v0, w0, visc, dt, K);                                           \

@@ -14,6 +14,7 @@
 // Build with: g++ -O2 -ffp-contract=off  (no -ffast-math) so every expression rounds exactly as
 // written; the HIP kernels are built with -ffp-contract=off too and must match bit for bit.
 #pragma once
+#include <cmath>
 #include <cstddef>
 #include <cstring>
 #include <utility>
@@ -258,6 +259,75 @@ void vel_step(int N, T* u, T* v, T* w, T* u0, T* v0, T* w0, T visc, T dt, int K)
     advect(N, 2, v, v0, u0, v0, w0, dt);
     advect(N, 3, w, w0, u0, v0, w0, dt);
     project(N, u, v, w, u0, v0, K, scratch.data());
+}
+
+// SPEC §6 tracers. pos = x0 y0 z0 x1 y1 z1 ... in grid-index coordinates.
+template <class T>
+struct TriSample {
+    size_t q000;
+    size_t dj, dk;
+    T s0, s1, t0, t1, r0, r1;
+    TriSample(int N, T x, T y, T z) {
+        Grid<T> g(N);
+        const T Nf = (T)N, lo = T(0.5), hi = Nf + T(0.5);
+        if (x < lo) x = lo;
+        if (x > hi) x = hi;
+        if (y < lo) y = lo;
+        if (y > hi) y = hi;
+        if (z < lo) z = lo;
+        if (z > hi) z = hi;
+        int i0 = (x == x) ? (int)x : 0, j0 = (y == y) ? (int)y : 0, k0 = (z == z) ? (int)z : 0;
+        i0 = i0 < 0 ? 0 : (i0 > N ? N : i0);
+        j0 = j0 < 0 ? 0 : (j0 > N ? N : j0);
+        k0 = k0 < 0 ? 0 : (k0 > N ? N : k0);
+        s1 = x - (T)i0;
+        s0 = T(1) - s1;
+        t1 = y - (T)j0;
+        t0 = T(1) - t1;
+        r1 = z - (T)k0;
+        r0 = T(1) - r1;
+        q000 = g.IX(i0, j0, k0);
+        dj = (size_t)g.S;
+        dk = (size_t)g.S * g.S;
+    }
+    T operator()(const T* d0) const {
+        const size_t q = q000;
+        return s0 * (t0 * (r0 * d0[q] + r1 * d0[q + dk]) + t1 * (r0 * d0[q + dj] + r1 * d0[q + dj + dk])) +
+               s1 * (t0 * (r0 * d0[q + 1] + r1 * d0[q + 1 + dk]) +
+                     t1 * (r0 * d0[q + 1 + dj] + r1 * d0[q + 1 + dj + dk]));
+    }
+};
+
+template <class T>
+inline T clamp_coord(int N, T x) {
+    const T lo = T(0.5), hi = (T)N + T(0.5);
+    if (x < lo) x = lo;
+    if (x > hi) x = hi;
+    return x;
+}
+
+template <class T>
+void tracers_sample(int N, int n, const T* pos, const T* dens, const T* u, const T* v, const T* w, T* dens_out,
+                    T* speed_out) {
+    for (int t = 0; t < n; ++t) {
+        const TriSample<T> S(N, pos[3 * t], pos[3 * t + 1], pos[3 * t + 2]);
+        const T a = S(u), b = S(v), c = S(w);
+        dens_out[t] = S(dens);
+        speed_out[t] = std::sqrt((a * a + b * b) + c * c);
+    }
+}
+
+template <class T>
+void tracers_advect(int N, int n, T* pos, const T* u, const T* v, const T* w, T dt) {
+    const T dt0 = dt * (T)N;
+    for (int t = 0; t < n; ++t) {
+        const T x = clamp_coord(N, pos[3 * t]), y = clamp_coord(N, pos[3 * t + 1]), z = clamp_coord(N, pos[3 * t + 2]);
+        const TriSample<T> S(N, x, y, z);
+        const T vx = S(u), vy = S(v), vz = S(w);
+        pos[3 * t] = clamp_coord(N, x + dt0 * vx);
+        pos[3 * t + 1] = clamp_coord(N, y + dt0 * vy);
+        pos[3 * t + 2] = clamp_coord(N, z + dt0 * vz);
+    }
 }
 
 }  // namespace sf_oracle

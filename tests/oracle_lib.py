@@ -83,3 +83,17 @@ def step(N, fields, dt, diff, visc, K):
     vel_step(f["u"], f["v"], f["w"], f["u0"], f["v0"], f["w0"], visc, dt, K)
     dens_step(f["dens"], f["dens0"], f["u"], f["v"], f["w"], diff, dt, K)
     return f
+
+
+def tracers_advect(pos, u, v, w, dt):
+    f, c = _fn("tracers_advect", u.dtype)
+    assert pos.dtype == u.dtype and pos.flags.c_contiguous
+    f(C.c_int(_n(u)), C.c_int(pos.shape[0]), _p(pos), _p(u), _p(v), _p(w), c(dt))
+
+
+def tracers_sample(pos, dens, u, v, w):
+    f, c = _fn("tracers_sample", u.dtype)
+    n = pos.shape[0]
+    d, s = np.zeros(n, u.dtype), np.zeros(n, u.dtype)
+    f(C.c_int(_n(u)), C.c_int(n), _p(pos), _p(dens), _p(u), _p(v), _p(w), _p(d), _p(s))
+    return d, s

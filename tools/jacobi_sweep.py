@@ -31,4 +31,4 @@ def run(N, dtype="f32", K=int(os.environ.get("SF_SWEEP_K", 20)), reps=int(os.env
 if __name__ == "__main__":
     sizes = [int(a) for a in sys.argv[1:]] or [512]
     for n in sizes:
-        run(n)
+        run(n, dtype=os.environ.get("SF_SWEEP_DTYPE", "f32"))
