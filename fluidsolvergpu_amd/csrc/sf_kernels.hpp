@@ -54,6 +54,28 @@ __device__ __forceinline__ void stv(T* p, typename VecT<T>::type v) {
     *reinterpret_cast<typename VecT<T>::type*>(p) = v;
 }
 
+// Value of the neighbouring lane across the whole 64-lane wave, as a DPP move (v_mov_b32 wave_shr:1 /
+// wave_shl:1 — a VALU modifier on gfx9-family ISAs incl. gfx950, no LDS round trip as ds_bpermute has).
+// lane_up: lane l receives lane l-1 (lane 0 receives 0); lane_dn: lane l receives lane l+1 (lane 63: 0).
+__device__ __forceinline__ float lane_up(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float lane_dn(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+}
+__device__ __forceinline__ double lane_up(double v) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffLL), 0x138, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x138, 0xf, 0xf, false);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double lane_dn(double v) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffLL), 0x130, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x130, 0xf, 0xf, false);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+
 // Offset of shell cell i = 0 of row (j, kl); cell i is at row0 + i.
 __device__ __forceinline__ long row0(const Geom& g, int j, int kl) {
     return (long)kl * g.plane + (long)j * g.px + (g.lead - 1);
@@ -397,8 +419,8 @@ __global__ void __launch_bounds__(256) jacobi_rb_kernel(Geom g, JacobiArgs<T, NF
             const int j = j0 + rj;
             V c = X[rk + 1][rj];
             // i-neighbours: adjacent lanes hold the adjacent vectors (shuffles run on every lane)
-            const T up = __shfl_up(c[W - 1], 1);
-            const T dn = __shfl_down(c[0], 1);
+            const T up = lane_up(c[W - 1]);
+            const T dn = lane_dn(c[0]);
             if (kl >= ke || j > N) continue;  // wave-uniform for tx >= 64; lanes of other rows otherwise
             const long q = planeq[rk + 1] + rowq[rj + 1];
             T last = c[0];
@@ -560,8 +582,8 @@ __global__ void __launch_bounds__(256, SF_J2_WAVES) jacobi2_kernel(Geom g, Jacob
         for (int r = -1; r <= RJ; ++r) {
             if (SF_DIST(c, RK) + SF_DIST(r, RJ) > 1) continue;
             const V cc = X[c + 2][r + 2];
-            const T up = __shfl_up(cc[W - 1], 1);
-            const T dn = __shfl_down(cc[0], 1);
+            const T up = lane_up(cc[W - 1]);
+            const T dn = lane_dn(cc[0]);
             const long q = planeq[c + 2] + rowq[r + 2];
             T xm, xp;
             if (first_vec)
@@ -607,8 +629,8 @@ __global__ void __launch_bounds__(256, SF_J2_WAVES) jacobi2_kernel(Geom g, Jacob
         for (int rj = 0; rj < RJ; ++rj) {
             const int j = j0 + rj;
             const V yc = Y[rk + 1][rj + 1];
-            const T up = __shfl_up(yc[W - 1], 1);
-            const T dn = __shfl_down(yc[0], 1);
+            const T up = lane_up(yc[W - 1]);
+            const T dn = lane_dn(yc[0]);
             T ym, yp;
             if (first_vec)
                 ym = sx * yc[0];
@@ -772,8 +794,8 @@ __global__ void __launch_bounds__(512) jacobi2m_kernel(Geom g, JacobiArgs<T, NF>
             const int j = jrow[p];
             if (r < 1 || r > TJ + 2 || j < 1 || j > N) continue;  // uniform per wave
             const V cc = xB[p];
-            const T up = __shfl_up(cc[W - 1], 1);
-            const T dn = __shfl_down(cc[0], 1);
+            const T up = lane_up(cc[W - 1]);
+            const T dn = lane_dn(cc[0]);
             T xm, xp;
             if (first_vec)
                 xm = m.ishell_mem ? x[pq + rowq[p] - 1] : sx * cc[0];
@@ -804,8 +826,8 @@ __global__ void __launch_bounds__(512) jacobi2m_kernel(Geom g, JacobiArgs<T, NF>
                 const int j = jrow[p];
                 if (r < 2 || r > TJ + 1 || j < 1 || j > N) continue;  // uniform per wave
                 const V yc = yB[p];
-                const T up = __shfl_up(yc[W - 1], 1);
-                const T dn = __shfl_down(yc[0], 1);
+                const T up = lane_up(yc[W - 1]);
+                const T dn = lane_dn(yc[0]);
                 T ym, yp;
                 if (first_vec)
                     ym = sx * yc[0];

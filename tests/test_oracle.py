@@ -269,3 +269,35 @@ def test_diffuse_conserves_mass_in_the_limit():
     x = x0.copy()
     O.diffuse(0, x, x0, 1e-3, DT, 4000)
     assert abs(x[1:-1, 1:-1, 1:-1].sum() - x0[1:-1, 1:-1, 1:-1].sum()) < 1e-9 * x0.sum()
+
+
+# ---- tracers (SPEC §6) -------------------------------------------------------------------------------------
+def test_tracers_zero_velocity_stay_put_and_are_clamped():
+    N = 6
+    z = np.zeros((N + 2,) * 3, np.float64)
+    pos = np.array([[1.25, 2.5, 3.75], [-3.0, 100.0, 0.5], [N + 0.5, 0.5, 3.0]])
+    p = pos.copy()
+    O.tracers_advect(p, z, z, z, 0.1)
+    assert np.array_equal(p, np.clip(pos, 0.5, N + 0.5))
+
+
+def test_tracers_uniform_velocity_translates():
+    N, dt = 8, 0.1
+    u = np.full((N + 2,) * 3, 0.5)
+    v = np.full((N + 2,) * 3, -0.25)
+    w = np.zeros((N + 2,) * 3)
+    p = np.array([[4.0, 4.0, 4.0], [2.5, 6.5, 1.5]])
+    q = p.copy()
+    O.tracers_advect(q, u, v, w, dt)
+    assert np.allclose(q, p + dt * N * np.array([0.5, -0.25, 0.0]), rtol=0, atol=1e-12)
+
+
+def test_tracer_sample_reproduces_a_trilinear_field_exactly():
+    N = 5
+    kk, jj, ii = np.meshgrid(*(np.arange(N + 2, dtype=np.float64),) * 3, indexing="ij")
+    lin = 0.5 * ii - 0.25 * jj + 2.0 * kk + 1.0  # exactly representable, trilinear interpolation is exact
+    z = np.zeros_like(lin)
+    pos = np.array([[1.5, 2.25, 3.125], [4.75, 0.5, 5.5], [3.0, 3.0, 3.0]])
+    d, s = O.tracers_sample(pos, lin, lin, z, z)
+    want = 0.5 * pos[:, 0] - 0.25 * pos[:, 1] + 2.0 * pos[:, 2] + 1.0
+    assert np.allclose(d, want, rtol=0, atol=1e-12) and np.allclose(s, np.abs(want), rtol=0, atol=1e-12)
