@@ -15,6 +15,12 @@
 // cloud of passive tracers is advected through the velocity field and written with write_point_mesh, the one
 // writer call the reference really makes (solver-unidyn.cu:487: ASCII, two point scalars).
 //
+// Several GPUs: start one process per GPU with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_PORT in the environment
+// (e.g. `python -m torch.distributed.run --no-python --nproc-per-node 8 ./sf_driver ...`). Rank 0 creates the
+// ncclUniqueId and hands it to the others through a file under /tmp keyed by MASTER_PORT (single node); every
+// rank then owns one k-slab and writes its own frames as anim_s_GPU<rank>_<frame>.vtk — the per-device naming
+// of solver-unidyn.cu:484-490 — as a rectilinear mesh carrying its z range.
+//
 //   sf_driver [--n 64] [--steps 20] [--iters 20] [--dtype f32|f64] [--every 10] [--out DIR]
 //             [--binary] [--device 0] [--slabs 1] [--plumbing] [--quiet] [--sync-output] [--tracers 0]
 #include <chrono>
@@ -26,6 +32,7 @@
 #include <sstream>
 #include <string>
 #include <thread>
+#include <unistd.h>
 #include <vector>
 
 #include "../../include/sf_visit_writer.h"
@@ -47,10 +54,50 @@ struct Options {
     int n = 64, steps = 20, iters = 20, every = 10, device = 0, slabs = 1, tracers = 0;
     bool f64 = false, binary = false, plumbing = false, quiet = false, sync_output = false;
     std::string out = ".";
+    int rank = 0, world = 1, local_rank = 0;
 };
+
+static int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+
+// Single-node exchange of the 128-byte ncclUniqueId: rank 0 writes it (atomically, via rename), the others poll.
+static void share_nccl_id(const Options& o, unsigned char* id) {
+    char path[256], tmp[300];
+    snprintf(path, sizeof path, "/tmp/sf_ncclid_%d_%s.bin", env_int("MASTER_PORT", 29500),
+             getenv("TORCHELASTIC_RUN_ID") ? getenv("TORCHELASTIC_RUN_ID") : "run");
+    if (o.rank == 0) {
+        if (sf_nccl_unique_id(id) != SF_OK) {
+            fprintf(stderr, "Error: sf_nccl_unique_id failed\n");
+            exit(1);
+        }
+        snprintf(tmp, sizeof tmp, "%s.tmp%d", path, (int)getpid());
+        FILE* f = fopen(tmp, "wb");
+        if (!f || fwrite(id, 1, SF_NCCL_ID_BYTES, f) != SF_NCCL_ID_BYTES || fclose(f) != 0 || rename(tmp, path) != 0) {
+            fprintf(stderr, "Error: cannot publish the nccl id at %s\n", path);
+            exit(1);
+        }
+    } else {
+        for (int tries = 0; tries < 600; ++tries) {  // up to 60 s
+            FILE* f = fopen(path, "rb");
+            if (f) {
+                const size_t n = fread(id, 1, SF_NCCL_ID_BYTES, f);
+                fclose(f);
+                if (n == SF_NCCL_ID_BYTES) return;
+            }
+            usleep(100000);
+        }
+        fprintf(stderr, "Error: rank %d timed out waiting for %s\n", o.rank, path);
+        exit(1);
+    }
+}
 
 static Options parse(int argc, char** argv) {
     Options o;
+    o.rank = env_int("RANK", 0);
+    o.world = env_int("WORLD_SIZE", 1);
+    o.local_rank = env_int("LOCAL_RANK", 0);
     for (int a = 1; a < argc; ++a) {
         const std::string s = argv[a];
         auto next = [&]() -> const char* {
@@ -112,14 +159,18 @@ static Inputs<T> make_inputs(int N, double dt, bool plumbing) {
     return in;
 }
 
+// One frame = the interior cells of global planes [kb, ke) (1-based k), density scalar + velocity vector, cell
+// centred. Single process: the whole cube as a regular mesh "anim_s<frame>.vtk". Several processes: each rank
+// writes its slab "anim_s_GPU<rank>_<frame>.vtk" as a rectilinear mesh whose z coordinates are its plane range.
 template <class T>
-static void write_frame(const Options& o, int frame, const std::vector<T>& dens, const std::vector<T>& u,
-                        const std::vector<T>& v, const std::vector<T>& w) {
+static void write_frame(const Options& o, int frame, int kb, int ke, const std::vector<T>& dens,
+                        const std::vector<T>& u, const std::vector<T>& v, const std::vector<T>& w) {
     const int N = o.n;
     const size_t S = (size_t)N + 2;
-    std::vector<float> d((size_t)N * N * N), vel((size_t)3 * N * N * N);
+    const size_t ncell = (size_t)N * N * (size_t)(ke - kb);
+    std::vector<float> d(ncell), vel(3 * ncell);
     size_t q = 0;
-    for (int k = 1; k <= N; ++k)
+    for (int k = kb; k < ke; ++k)
         for (int j = 1; j <= N; ++j)
             for (int i = 1; i <= N; ++i, ++q) {
                 const size_t s = (size_t)i + S * ((size_t)j + S * (size_t)k);
@@ -129,13 +180,22 @@ static void write_frame(const Options& o, int frame, const std::vector<T>& dens,
                 vel[3 * q + 2] = (float)w[s];
             }
     std::ostringstream oss;
-    oss << o.out << "/anim_s" << frame << ".vtk";
-    const std::string name = oss.str();
-    int dims[3] = {N + 1, N + 1, N + 1};  // point counts; cells = N^3 (visit_writer.cpp:901-905)
     int vardim[2] = {1, 3}, centering[2] = {0, 0};
     const char* names[2] = {"density", "velocity"};
     float* vars[2] = {d.data(), vel.data()};
-    write_regular_mesh(name.c_str(), o.binary ? 1 : 0, dims, 2, vardim, centering, names, vars);
+    if (o.world == 1) {
+        oss << o.out << "/anim_s" << frame << ".vtk";
+        int dims[3] = {N + 1, N + 1, N + 1};  // point counts; cells = N^3 (visit_writer.cpp:901-905)
+        write_regular_mesh(oss.str().c_str(), o.binary ? 1 : 0, dims, 2, vardim, centering, names, vars);
+    } else {
+        oss << o.out << "/anim_s_GPU" << o.rank << "_" << frame << ".vtk";  // solver-unidyn.cu:484
+        int dims[3] = {N + 1, N + 1, ke - kb + 1};
+        std::vector<float> xs(N + 1), zs(ke - kb + 1);
+        for (int a = 0; a <= N; ++a) xs[a] = (float)a;
+        for (int a = 0; a <= ke - kb; ++a) zs[a] = (float)(kb - 1 + a);
+        write_rectilinear_mesh(oss.str().c_str(), o.binary ? 1 : 0, dims, xs.data(), xs.data(), zs.data(), 2, vardim,
+                               centering, names, vars);
+    }
 }
 
 template <class T>
@@ -149,18 +209,27 @@ static int run(const Options& o) {
     p.dt = dt;
     p.diff = diff;
     p.visc = visc;
-    p.device = o.device;
+    p.device = o.world > 1 ? o.local_rank : o.device;
     p.nslabs_local = o.slabs;
-    p.rank = 0;
-    p.nranks = 1;
+    p.rank = o.rank;
+    p.nranks = o.world;
+    unsigned char nccl_id[SF_NCCL_ID_BYTES];
+    if (o.world > 1) {
+        share_nccl_id(o, nccl_id);
+        p.nccl_id = nccl_id;
+    }
     int rc = sf_create(&g_ctx, &p);
     if (rc != SF_OK) {
         fprintf(stderr, "Error %s (%s) at line %d in file %s\n", sf_status_string(rc), sf_last_error(nullptr),
                 __LINE__, __FILE__);
         exit(1);
     }
-    std::cout << sf_version() << "  N=" << o.n << " K=" << o.iters << " dtype=" << (sizeof(T) == 4 ? "f32" : "f64")
-              << " slabs=" << o.slabs << "\n";
+    const bool talk = (o.rank == 0);
+    if (talk)
+        std::cout << sf_version() << "  N=" << o.n << " K=" << o.iters << " dtype=" << (sizeof(T) == 4 ? "f32" : "f64")
+                  << " slabs=" << o.slabs * o.world << " ranks=" << o.world << "\n";
+    int own_kb = 1, own_ke = o.n + 1;
+    SF_CHECK_RETURN(sf_owned_planes(g_ctx, &own_kb, &own_ke));
 
     Inputs<T> in = make_inputs<T>(o.n, dt, o.plumbing);
     SF_CHECK_RETURN(sf_upload(g_ctx, SF_U, in.u.data()));
@@ -180,7 +249,7 @@ static int run(const Options& o) {
 
     // tracers: a small lattice in the middle of the box, in grid-index coordinates (SPEC §6)
     std::vector<T> tpos, tdens, tspeed;
-    if (o.tracers > 0 && o.slabs == 1) {
+    if (o.tracers > 0 && o.slabs == 1 && o.world == 1) {
         int side = 1;
         while (side * side * side < o.tracers) ++side;
         for (int c = 0; c < side && (int)tpos.size() / 3 < o.tracers; ++c)
@@ -215,7 +284,7 @@ static int run(const Options& o) {
     double total_ms = 0;
     const auto wall0 = std::chrono::steady_clock::now();
     for (int t = 0; t < o.steps; t++) {
-        if (!o.quiet) std::cout << "t= " << t << "\n";
+        if (!o.quiet && talk) std::cout << "t= " << t << "\n";
         float elapsedTime = 0.f;
         SF_CHECK_RETURN(sf_timer_start(g_ctx));
         SF_CHECK_RETURN(sf_copy_field(g_ctx, SF_U0, SF_USER0));
@@ -227,7 +296,7 @@ static int run(const Options& o) {
         if (ntr > 0) SF_CHECK_RETURN(sf_tracers_advect(g_ctx));
         SF_CHECK_RETURN(sf_timer_stop(g_ctx, &elapsedTime));
         total_ms += elapsedTime;
-        if (!o.quiet) std::cout << "done.\nElapsed kernel time: " << elapsedTime << " ms\n";
+        if (!o.quiet && talk) std::cout << "done.\nElapsed kernel time: " << elapsedTime << " ms\n";
 
         if (o.every > 0 && t % o.every == 0) {
             const int frame = t / o.every;
@@ -239,7 +308,7 @@ static int run(const Options& o) {
                 SF_CHECK_RETURN(sf_download(g_ctx, SF_U, hu.data()));
                 SF_CHECK_RETURN(sf_download(g_ctx, SF_V, hv.data()));
                 SF_CHECK_RETURN(sf_download(g_ctx, SF_W, hw.data()));
-                write_frame<T>(o, frame, hd, hu, hv, hw);
+                write_frame<T>(o, frame, own_kb, own_ke, hd, hu, hv, hw);
                 if (ntr > 0) write_tracers(frame);
             } else {
                 const int fields[4] = {SF_DENS, SF_U, SF_V, SF_W};
@@ -251,7 +320,7 @@ static int run(const Options& o) {
                             fprintf(stderr, "Error: snapshot read failed for frame %d\n", frame);
                             exit(1);
                         }
-                    write_frame<T>(o, frame, hd, hu, hv, hw);
+                    write_frame<T>(o, frame, own_kb, own_ke, hd, hu, hv, hw);
                     if (ntr > 0) write_tracers(frame);
                 });
             }
@@ -260,10 +329,10 @@ static int run(const Options& o) {
     if (writer.joinable()) writer.join();
     SF_CHECK_RETURN(sf_sync(g_ctx));
     const double wall_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count();
-    std::cout << "wall time of the loop incl. output: " << wall_s << " s ("
+    if (talk) std::cout << "wall time of the loop incl. output: " << wall_s << " s ("
               << (o.sync_output ? "synchronous" : "asynchronous") << " output)\n";
     const double cells = (double)o.n * o.n * o.n;
-    if (o.steps > 0)
+    if (o.steps > 0 && talk)
         std::cout << "mean step " << total_ms / o.steps << " ms, " << cells * o.steps / (total_ms * 1e-3) / 1e6
                   << " Mcells/s\n";
     sf_destroy(g_ctx);
