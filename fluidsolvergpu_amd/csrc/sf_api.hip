@@ -16,6 +16,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <climits>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -170,7 +171,17 @@ public:
             sl.geom.wall_lo = (sl.gid == 0);
             sl.geom.wall_hi = (sl.gid == P_ - 1);
             SF_HIP(hipStreamCreateWithFlags(&sl.cs, hipStreamNonBlocking));
-            SF_HIP(hipStreamCreateWithFlags(&sl.hs, hipStreamNonBlocking));
+            {
+                // SF_HALO_PRIO=1 gives the halo stream the highest priority so its traffic does not queue behind the
+                // interior sweep. Off by default: with logical slabs on ONE GPU it doubles the step time (the copy
+                // kernel pre-empts the sweeps); whether it pays with RCCL across GPUs is still to be measured.
+                int lo = 0, hi = 0;
+                SF_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+                if (env_int("SF_HALO_PRIO", 0))
+                    SF_HIP(hipStreamCreateWithPriority(&sl.hs, hipStreamNonBlocking, hi));
+                else
+                    SF_HIP(hipStreamCreateWithFlags(&sl.hs, hipStreamNonBlocking));
+            }
             SF_HIP(hipEventCreateWithFlags(&sl.boundary_done, hipEventDisableTiming));
             SF_HIP(hipEventCreateWithFlags(&sl.halo_done, hipEventDisableTiming));
             for (int f = 0; f < SF_USER0; ++f) sl.field[f] = alloc_field();
@@ -694,6 +705,8 @@ private:
         m.band = (jacobi_mode_ >= 2 && m.gy >= 16) ? ceil_div(m.gy, 8) : 0;
         m.ishell_mem = 1;
         m.ishell_write = 1;
+        m.split = split_;
+        m.gap = gap_;
         const long per_plane = m.band > 0 ? (long)m.nxcd * m.gx * m.band : (long)m.gx * m.gy;
         nblocks = (unsigned)(per_plane * nplanes);
         return m;
@@ -703,7 +716,10 @@ private:
     // slab-boundary planes go first, their completion is recorded, and the rest follows so that the
     // halo exchange issued by the caller overlaps the interior work.
     template <class F>
-    void for_planes(F launch, int depth = 1) {
+    void for_planes(F launch, int depth = 1, bool can_split = true) {
+        // the exchange that follows ships G_ planes per side, so at least G_ planes per side must come out of
+        // the boundary launch (whose completion the halo stream waits for), not out of the interior launch
+        depth = std::max(depth, G_);
         const int kb = G_, ke = G_ + nzl_;
         if (P_ == 1) {
             launch(slabs_[0], kb, ke);
@@ -714,9 +730,19 @@ private:
             if (nzl_ <= 2 * depth) {
                 launch(sl, kb, ke);
                 SF_HIP(hipEventRecord(sl.boundary_done, sl.cs));
-            } else {
+            } else if (!can_split || !env_int("SF_SPLIT", 1)) {
                 launch(sl, kb, kb + depth);
                 launch(sl, ke - depth, ke);
+                SF_HIP(hipEventRecord(sl.boundary_done, sl.cs));
+                launch(sl, kb + depth, ke - depth);
+            } else {
+                // ONE launch over the first and the last `depth` interior planes (split plane range), then the
+                // interior, which overlaps the halo exchange the caller issues next
+                split_ = depth;
+                gap_ = nzl_ - 2 * depth;
+                launch(sl, kb, kb + 2 * depth);
+                split_ = INT_MAX;
+                gap_ = 0;
                 SF_HIP(hipEventRecord(sl.boundary_done, sl.cs));
                 launch(sl, kb + depth, ke - depth);
             }
@@ -741,15 +767,25 @@ private:
             const bool lo_local = has_lo && s > 0, hi_local = has_hi && s < L_ - 1;
             if (lo_local) SF_HIP(hipStreamWaitEvent(sl.hs, slabs_[s - 1].boundary_done, 0));
             if (hi_local) SF_HIP(hipStreamWaitEvent(sl.hs, slabs_[s + 1].boundary_done, 0));
-            // pull from neighbours that live in this process
-            for (int f = 0; f < NF; ++f) {
-                T* mine = sl.field[fields[f]];
-                if (lo_local)
-                    SF_HIP(hipMemcpyAsync(mine + recv_lo, slabs_[s - 1].field[fields[f]] + send_hi, bytes,
-                                          hipMemcpyDeviceToDevice, sl.hs));
-                if (hi_local)
-                    SF_HIP(hipMemcpyAsync(mine + recv_hi, slabs_[s + 1].field[fields[f]] + send_lo, bytes,
-                                          hipMemcpyDeviceToDevice, sl.hs));
+            // pull from neighbours that live in this process: one copy kernel for all fields and both sides
+            if (lo_local || hi_local) {
+                sfk::HaloCopyArgs H;
+                H.nseg = 0;
+                H.n16 = (long)(bytes / 16);
+                for (int f = 0; f < NF; ++f) {
+                    T* mine = sl.field[fields[f]];
+                    if (lo_local) {
+                        H.src[H.nseg] = reinterpret_cast<const float4*>(slabs_[s - 1].field[fields[f]] + send_hi);
+                        H.dst[H.nseg++] = reinterpret_cast<float4*>(mine + recv_lo);
+                    }
+                    if (hi_local) {
+                        H.src[H.nseg] = reinterpret_cast<const float4*>(slabs_[s + 1].field[fields[f]] + send_lo);
+                        H.dst[H.nseg++] = reinterpret_cast<float4*>(mine + recv_hi);
+                    }
+                }
+                const unsigned gx = (unsigned)std::max(1L, std::min((H.n16 + 255) / 256, 512L));
+                hipLaunchKernelGGL(sfk::halo_copy_kernel, dim3(gx, H.nseg), dim3(256), 0, sl.hs, H);
+                SF_HIP(hipGetLastError());
             }
             // neighbours in other processes: grouped send/recv over RCCL (xGMI point-to-point)
             const bool lo_remote = has_lo && !lo_local, hi_remote = has_hi && !hi_local;
@@ -816,6 +852,8 @@ private:
         m.band = (jacobi_mode_ >= 2 && m.gy >= 16) ? ceil_div(m.gy, 8) : 0;
         m.ishell_mem = (!ishell_skip_ || first) ? 1 : 0;
         m.ishell_write = (!ishell_skip_ || last) ? 1 : 0;
+        m.split = split_;
+        m.gap = gap_;
         const long per_plane = m.band > 0 ? (long)m.nxcd * m.gx * m.band : (long)m.gx * m.gy;
         const long nblocks = per_plane * ceil_div(ke - kb, RK) * NF;
         hipLaunchKernelGGL((sfk::jacobi_rb_kernel<T, NF, NT, RJ, RK>), dim3((unsigned)nblocks), dim3(tx, ty), 0,
@@ -826,7 +864,8 @@ private:
     void launch_rb_shape(Slab& sl, const sfk::JacobiArgs<T, NF>& A, int kb, int ke, bool first, bool last) {
         // measured (512^3 / 256^3 fp32): 2x2 blocks win once the sweep streams from HBM (286 vs 309 us),
         // 1x1 wins while x, x0, x' sit in the Infinity Cache (30.8 vs 34.0 us)
-        const int shape = rb_shape_ > 0 ? rb_shape_ : (NT ? 22 : 11);
+        int shape = rb_shape_ > 0 ? rb_shape_ : (NT ? 22 : 11);
+        if (split_ != INT_MAX && split_ % 2 != 0) shape = 11;  // a plane block must not straddle the split
         switch (shape) {
             case 11: launch_rb<NF, NT, 1, 1>(sl, A, kb, ke, first, last); break;
             case 21: launch_rb<NF, NT, 2, 1>(sl, A, kb, ke, first, last); break;
@@ -874,6 +913,8 @@ private:
         m.band = (jacobi_mode_ >= 2 && m.gy >= 16) ? ceil_div(m.gy, 8) : 0;
         m.ishell_mem = (!ishell_skip_ || first) ? 1 : 0;
         m.ishell_write = (!ishell_skip_ || last) ? 1 : 0;
+        m.split = split_;
+        m.gap = gap_;
         const long per_plane = m.band > 0 ? (long)m.nxcd * m.band : (long)m.gy;
         const long nblocks = per_plane * ceil_div(ke - kb, RK) * NF;
         hipLaunchKernelGGL((sfk::jacobi2_kernel<T, NF, NT, RJ, RK>), dim3((unsigned)nblocks), dim3(tx, ty), 0, sl.cs,
@@ -895,6 +936,8 @@ private:
         m.band = (jacobi_mode_ >= 2 && m.gy >= 16) ? ceil_div(m.gy, 8) : 0;
         m.ishell_mem = (!ishell_skip_ || first) ? 1 : 0;
         m.ishell_write = (!ishell_skip_ || last) ? 1 : 0;
+        m.split = split_;
+        m.gap = gap_;
         const int kc = std::max(1, std::min(kc2_, ke - kb));
         const long per_plane = m.band > 0 ? (long)m.nxcd * m.band : (long)m.gy;
         const long nblocks = per_plane * ceil_div(ke - kb, kc) * NF;
@@ -959,7 +1002,7 @@ private:
                     launch_jacobi2<NF>(sl, A, kb, ke, it == 0, it + step == K);
                 else
                     launch_jacobi<NF>(sl, A, kb, ke, it == 0, it + step == K);
-            }, step);
+            }, step, jacobi_mode_ != 0);
             // the new iterate becomes the field; the old buffer becomes scratch
             for (Slab& sl : slabs_)
                 for (int f = 0; f < NF; ++f) std::swap(sl.field[x[f]], sl.scratch[f]);
@@ -1046,6 +1089,7 @@ private:
 
     int N_, K_, device_;
     int L_ = 1, nranks_ = 1, rank_ = 0, P_ = 1, G_ = 1;
+    int split_ = INT_MAX, gap_ = 0;  // plane-range split of the launch being issued (for_planes)
     T dt_{}, diff_{}, visc_{};
     int num_cu_ = 256;
     int nzl_ = 0, lead_ = 0, px_ = 0, nplanes_ = 0, kchunk_ = 0, jacobi_mode_ = 2, tx_override_ = 0, nt_mode_ = 2, rb_shape_ = 0;

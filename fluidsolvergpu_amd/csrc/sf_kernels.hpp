@@ -289,7 +289,16 @@ struct TileMap {
     int nxcd;          // 8 when banded
     int ishell_mem;    // read x[0], x[N+1] from memory (first sweep: x is caller data)
     int ishell_write;  // write the i = 0 / N+1 shell cells of x' (last sweep)
+    // A launch covers `ke - kb` logical planes t = 0 .. ; plane t sits at kb + t + (t >= split ? gap : 0), which
+    // lets ONE launch sweep the first and the last planes of a slab (the halo-critical ones). split is a multiple
+    // of the kernel's plane block; no split: split = INT_MAX, gap = 0.
+    int split;
+    int gap;
 };
+
+__device__ __forceinline__ int plane_of(const TileMap& m, int kb, int t) {
+    return kb + t + (t >= m.split ? m.gap : 0);
+}
 
 // Workgroup -> (i-tile, j-tile, plane, extra) for the 1-D banded grid. Returns false for padding tiles.
 __device__ __forceinline__ bool flat_tile(const TileMap& m, int nk, int& it, int& jt, int& kk, int& f) {
@@ -318,7 +327,7 @@ __device__ __forceinline__ bool flat_cell(const Geom& g, const TileMap& m, int k
                                           int& kl, int& nv) {
     int it, jt, kk, f;
     if (!flat_tile(m, ke - kb, it, jt, kk, f)) return false;
-    kl = kb + kk;
+    kl = plane_of(m, kb, kk);
     i0 = 1 + W * (it * (int)blockDim.x + (int)threadIdx.x);
     j = 1 + jt * (int)blockDim.y + (int)threadIdx.y;
     if (i0 > g.N || j > g.N) return false;
@@ -354,7 +363,11 @@ __global__ void __launch_bounds__(256) jacobi_rb_kernel(Geom g, JacobiArgs<T, NF
         if (jt >= m.gy) return;
     }
     const int N = g.N;
-    const int k0 = kb + kk * RK;
+    const int k0 = plane_of(m, kb, kk * RK);
+    {
+        const int left = (ke - kb) - kk * RK;  // logical planes left in this launch from this block on
+        ke = k0 + (left < RK ? left : RK);     // from here on: physical end of this block's planes
+    }
     const int i0 = 1 + W * (it * (int)blockDim.x + (int)threadIdx.x);
     const int j0 = 1 + (jt * (int)blockDim.y + (int)threadIdx.y) * RJ;
     if (i0 > N || j0 > N) return;
@@ -510,7 +523,11 @@ __global__ void __launch_bounds__(256, SF_J2_WAVES) jacobi2_kernel(Geom g, Jacob
     }
     const int N = g.N;
     const int nvec = N / W;
-    const int k0 = kb + kk * RK;
+    const int k0 = plane_of(m, kb, kk * RK);
+    {
+        const int left = (ke - kb) - kk * RK;
+        ke = k0 + (left < RK ? left : RK);  // physical end of this block's planes
+    }
     const bool tile_ok = jt < m.gy;  // uniform per workgroup
     int vec = (int)threadIdx.x;
     int j0 = 1 + (jt * (int)blockDim.y + (int)threadIdx.y) * RJ;
@@ -1184,6 +1201,29 @@ __global__ void __launch_bounds__(256) fill_kernel(T* __restrict__ x, T value, l
     for (int e = 0; e < W; ++e) v[e] = value;
     const long stride = (long)gridDim.x * blockDim.x;
     for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < nvec; q += stride) stv(x + q * W, v);
+}
+
+// Ghost-plane copies between logical slabs of one process: up to 6 (field, direction) segments in one launch.
+struct HaloCopyArgs {
+    const float4* src[6];
+    float4* dst[6];
+    int nseg;
+    long n16;  // 16-byte units per segment
+};
+
+__global__ void __launch_bounds__(256) halo_copy_kernel(HaloCopyArgs A) {
+    const int seg = (int)blockIdx.y;
+    if (seg >= A.nseg) return;
+    const float4* __restrict__ s = A.src[0];
+    float4* __restrict__ d = A.dst[0];
+#pragma unroll
+    for (int q = 1; q < 6; ++q)
+        if (seg == q) {
+            s = A.src[q];
+            d = A.dst[q];
+        }
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < A.n16; q += stride) d[q] = s[q];
 }
 
 // float4 copy used to quote the achievable HBM rate in the same run as the solver numbers.
