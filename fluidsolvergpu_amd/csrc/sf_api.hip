@@ -1061,20 +1061,18 @@ private:
             ensure(sl, p);
             SF_HIP(hipMemsetAsync(sl.field[p], 0, (size_t)field_elems_ * sizeof(T), sl.cs));
         }
-        // div is also evaluated on the first ghost plane either side (not on physical shells) when sweep pairs
-        // are fused across slabs: the fused kernel's first sweep needs x0 = div there, and recomputing it from
-        // the depth-2 ghosts of u,v,w is cheaper than another exchange. No exchange follows, so one launch.
-        for (Slab& sl : slabs_) {
-            const int kb = G_ - ((G_ == 2 && !sl.geom.wall_lo) ? 1 : 0);
-            const int ke = G_ + nzl_ + ((G_ == 2 && !sl.geom.wall_hi) ? 1 : 0);
+        for_planes([&](Slab& sl, int kb, int ke) {
             dim3 block;
             unsigned nblocks;
             const sfk::TileMap m = flat_map(ke - kb, block, nblocks);
             hipLaunchKernelGGL((sfk::project_div_kernel<T>), dim3(nblocks), block, 0, sl.cs, sl.geom, args(sl), kb, ke, m);
-        }
-        SF_HIP(hipGetLastError());
-        // no exchange here: lin_solve reads div only at cell centres, and p is zero, ghosts included
+        });
+        // div's ghost planes are exchanged although a single sweep reads div at cell centres only: the fused
+        // sweep pair evaluates its first sweep on the first ghost plane and needs x0 = div there, and div is left
+        // in the v0 slot, where the caller may use it as the next step's source / initial guess (all G planes).
+        // p is zero, ghosts included.
         const int dv[1] = {div};
+        exchange<1>(dv);
         const int ps[1] = {p}, b0[1] = {0};
         op_lin_solve<1>(ps, dv, b0, T(1), T(6), K_);
         for_planes([&](Slab& sl, int kb, int ke) {

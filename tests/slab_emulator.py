@@ -1,8 +1,8 @@
 """Test helper: numpy model of the slab-decomposed step (docs/SPEC.md §4) with a pluggable halo transport.
 
 It follows the EXCHANGE SCHEDULE of the product (fluidsolvergpu_amd/csrc/sf_api.hip: op_add_source has
-no exchange, op_lin_solve exchanges after every sweep, project_div has none, project_sub and op_advect
-exchange their outputs) on local arrays of shape (nzl+2, S, S) — interior planes 1..nzl, ghosts 0 and
+no exchange, op_lin_solve exchanges after every sweep, project_div / project_sub / op_advect exchange their
+outputs) on local arrays of shape (nzl+2, S, S) — interior planes 1..nzl, ghosts 0 and
 nzl+1 — so a world_size-2 gloo run on CPU can check that this schedule reproduces the undecomposed
 oracle bit for bit. Test infrastructure only."""
 import numpy as np
@@ -121,7 +121,8 @@ class Slab:
         p[...] = 0
         div[Kc, I, I] = c_div * (((u[Kc, I, 2:N + 2] - u[Kc, I, 0:N]) + (v[Kc, 2:N + 2, I] - v[Kc, 0:N, I]))
                                  + (w[2:nzl + 2, I, I] - w[0:nzl, I, I]))
-        self.set_bnd(0, div)  # no exchange: lin_solve reads div at cell centres only
+        self.set_bnd(0, div)
+        self.exchange(div)  # as the product does: div stays in the v0 slot and may be next step's source
         (p_new,) = self.lin_solve(0, [p], [div], 1, 6, K)
         p[...] = p_new
         u[Kc, I, I] = u[Kc, I, I] - c_grad * (p[Kc, I, 2:N + 2] - p[Kc, I, 0:N])

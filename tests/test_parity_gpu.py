@@ -219,6 +219,34 @@ def test_slabs_fused_pairs_two_ghost_planes(N, P, K, steps, dtype):
         assert_same(got[n], f[n], f"P={P} fused: {n}")
 
 
+@pytest.mark.parametrize("prio", ["0", "1"])
+@pytest.mark.parametrize("N,P,K", [(128, 2, 6), (128, 8, 5), (192, 4, 4), (256, 8, 3)])
+def test_slabs_stress_against_single_slab(N, P, K, prio, monkeypatch):
+    """Timing-sensitive check of the halo overlap: large interior launches run concurrently with the exchange.
+    The decomposed run must equal the single-slab GPU run bit for bit, with the halo stream at normal and at
+    highest priority (the latter exposed a missing dependency during development), repeated."""
+    dtype = np.float32
+    monkeypatch.setenv("SF_HALO_PRIO", prio)
+    f = small_velocity(rand_fields(N, dtype, 40 + P), N, dtype)
+
+    def run(nslabs):
+        with make(N, dtype, K=K, nslabs_local=nslabs) as fs:
+            for n in NAMES:
+                fs.upload(n, f[n])
+            for _ in range(2):
+                fs.copy_field("user0", "u")  # extra traffic on the compute stream between steps
+                fs.vel_step()
+                fs.dens_step()
+            fs.sync()
+            return {n: fs.download(n) for n in ("u", "v", "w", "dens")}
+
+    want = run(1)
+    for rep in range(2):
+        got = run(P)
+        for n in want:
+            assert_same(got[n], want[n], f"N={N} P={P} prio={prio} rep={rep}: {n}")
+
+
 def test_upload_planes_fills_all_ghosts():
     """A rank that fills exactly sf_stored_planes() with sf_upload_planes gets the same state as sf_upload."""
     N, dtype, P = 16, np.float32, 4
