@@ -693,12 +693,14 @@ private:
 
     // 1-D banded grid for the one-vector-per-thread kernels: fills block, returns the map and block count.
     sfk::TileMap flat_map(int nplanes, dim3& block, unsigned& nblocks) const {
+        // these kernels take their i+-1 values by loads, so a row tile may have any width: one tile per row up
+        // to 256 vectors (no idle lanes for N = 324, 408, ...), 64-lane tiles beyond
         const int nvec = ceil_div(N_, W);
-        int tx = 1;
-        while (tx < nvec && tx < 64) tx <<= 1;
-        const int ty = 256 / tx;
+        const int tx = nvec <= 256 ? nvec : 64;
+        const int ty = std::max(1, 256 / tx);
         block = dim3(tx, ty, 1);
         sfk::TileMap m;
+        m.rows = 0;
         m.gx = ceil_div(nvec, tx);
         m.gy = ceil_div(N_, ty);
         m.nxcd = 8;
@@ -904,11 +906,10 @@ private:
     template <int NF, bool NT, int RJ, int RK>
     void launch_fused2(Slab& sl, const sfk::JacobiArgs<T, NF>& A, int kb, int ke, bool first, bool last) {
         const int nvec = N_ / W;
-        const int tx = ceil_div(nvec, 64) * 64;
-        const int ty = std::max(1, 256 / tx);
         sfk::TileMap m;
+        m.rows = std::max(1, 256 / nvec);  // row strips per 256-thread workgroup
         m.gx = 1;
-        m.gy = ceil_div(N_, ty * RJ);
+        m.gy = ceil_div(N_, m.rows * RJ);
         m.nxcd = 8;
         m.band = (jacobi_mode_ >= 2 && m.gy >= 16) ? ceil_div(m.gy, 8) : 0;
         m.ishell_mem = (!ishell_skip_ || first) ? 1 : 0;
@@ -917,8 +918,12 @@ private:
         m.gap = gap_;
         const long per_plane = m.band > 0 ? (long)m.nxcd * m.band : (long)m.gy;
         const long nblocks = per_plane * ceil_div(ke - kb, RK) * NF;
-        hipLaunchKernelGGL((sfk::jacobi2_kernel<T, NF, NT, RJ, RK>), dim3((unsigned)nblocks), dim3(tx, ty), 0, sl.cs,
-                           sl.geom, A, kb, ke, m);
+        if (nvec % 64 != 0 && 64 % nvec != 0)
+            hipLaunchKernelGGL((sfk::jacobi2_kernel<T, NF, NT, RJ, RK, true>), dim3((unsigned)nblocks), dim3(256), 0,
+                               sl.cs, sl.geom, A, kb, ke, m);
+        else
+            hipLaunchKernelGGL((sfk::jacobi2_kernel<T, NF, NT, RJ, RK, false>), dim3((unsigned)nblocks), dim3(256), 0,
+                               sl.cs, sl.geom, A, kb, ke, m);
     }
 
     // LDS-staged marching form: rows of up to 128 vectors (blockDim = NV x 4 <= 512 threads).
@@ -965,13 +970,8 @@ private:
 
     template <int NF, bool NT>
     void launch_fused2_shape(Slab& sl, const sfk::JacobiArgs<T, NF>& A, int kb, int ke, bool first, bool last) {
-        switch (f2_shape_) {
-            case 21: launch_fused2<NF, NT, 2, 1>(sl, A, kb, ke, first, last); break;
-            case 12: launch_fused2<NF, NT, 1, 2>(sl, A, kb, ke, first, last); break;
-            case 11: launch_fused2<NF, NT, 1, 1>(sl, A, kb, ke, first, last); break;
-            case 42: launch_fused2<NF, NT, 4, 2>(sl, A, kb, ke, first, last); break;
-            default: launch_fused2<NF, NT, 2, 2>(sl, A, kb, ke, first, last); break;
-        }
+        // 2x2 output vectors per thread: measured best of 1x1, 2x1, 1x2, 2x2, 4x2 (4x2 spills)
+        launch_fused2<NF, NT, 2, 2>(sl, A, kb, ke, first, last);
     }
 
     // K Jacobi sweeps on NF fields at once; scratch buffers are swapped into the slots.

@@ -294,6 +294,7 @@ struct TileMap {
     // of the kernel's plane block; no split: split = INT_MAX, gap = 0.
     int split;
     int gap;
+    int rows;  // jacobi2_kernel: row strips per workgroup (256 threads hold `rows` strips of N/W vectors each)
 };
 
 __device__ __forceinline__ int plane_of(const TileMap& m, int kb, int t) {
@@ -497,14 +498,20 @@ __global__ void __launch_bounds__(256) jacobi_rb_kernel(Geom g, JacobiArgs<T, NF
 #ifndef SF_J2_WAVES
 #define SF_J2_WAVES 2
 #endif
-template <class T, int NF, bool NT, int RJ, int RK>
+// XLDS: hand the x end cells across wave seams through LDS (one extra barrier) instead of masked per-lane loads.
+// Pays when rows start anywhere inside a wave (row width not a multiple of 64 vectors: both ends of most waves
+// are seams); with rows of 64 / 128 vectors each wave has at most one seam and the loads are cheaper.
+template <class T, int NF, bool NT, int RJ, int RK, bool XLDS>
 __global__ void __launch_bounds__(256, SF_J2_WAVES) jacobi2_kernel(Geom g, JacobiArgs<T, NF> A, int kb, int ke,
                                                        TileMap m) {
     constexpr int W = VecT<T>::W;
     typedef typename VecT<T>::type V;
     constexpr int NPOS = RJ * RK;
-    __shared__ T sh_first[4][NPOS];  // [wave][output position]: y of the wave's first cell
-    __shared__ T sh_last[4][NPOS];   //                          y of the wave's last cell
+    constexpr int NYPOS = (RK + 2) * (RJ + 2);
+    __shared__ T sh_first[4][NPOS];    // [wave][output position]: y of the wave's first cell
+    __shared__ T sh_last[4][NPOS];     //                          y of the wave's last cell
+    __shared__ T shx_first[4][NYPOS];  // [wave][first-sweep position]: x of the wave's first / last cell
+    __shared__ T shx_last[4][NYPOS];
     int jt, kk, f;
     {
         int r = (int)blockIdx.x;
@@ -529,13 +536,16 @@ __global__ void __launch_bounds__(256, SF_J2_WAVES) jacobi2_kernel(Geom g, Jacob
         ke = k0 + (left < RK ? left : RK);  // physical end of this block's planes
     }
     const bool tile_ok = jt < m.gy;  // uniform per workgroup
-    int vec = (int)threadIdx.x;
-    int j0 = 1 + (jt * (int)blockDim.y + (int)threadIdx.y) * RJ;
-    const bool active = tile_ok && vec < nvec && j0 <= N;
+    // 256 threads in a line hold m.rows row strips of nvec vectors each: rows need not start at a wave
+    // boundary, so a wave seam can fall anywhere inside a row (handled through LDS below)
+    const int tid = (int)threadIdx.x;
+    const int strip = tid / nvec;
+    int vec = tid - strip * nvec;
+    int j0 = 1 + (jt * m.rows + strip) * RJ;
+    const bool active = tile_ok && strip < m.rows && j0 <= N;
     // out-of-range threads keep running on clamped (valid) addresses so that every wave reaches the
-    // barrier and every shuffle source lane is alive; they store nothing
-    vec = vec < nvec ? vec : nvec - 1;
-    j0 = (tile_ok && j0 <= N) ? j0 : N;
+    // barrier and every DPP source lane is alive; they store nothing
+    j0 = (tile_ok && strip < m.rows && j0 <= N) ? j0 : N;
     const int i0 = 1 + W * vec;
     const T a = A.a, inv = A.inv;
     const T* __restrict__ x = A.x[0];
@@ -585,11 +595,24 @@ __global__ void __launch_bounds__(256, SF_J2_WAVES) jacobi2_kernel(Geom g, Jacob
         for (int r = -1; r <= RJ; ++r)
             if (SF_DIST(c, RK) + SF_DIST(r, RJ) <= 1) S[c + 1][r + 1] = ldv(x0 + planeq[c + 2] + rowq[r + 2]);
 
-    const int lane = (int)threadIdx.x & 63;
-    // LDS slot of this wave: rows of the workgroup are stacked, waves of one row are adjacent slots
-    const int wave = (int)threadIdx.y * ((int)blockDim.x >> 6) + ((int)threadIdx.x >> 6);
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
     const bool first_vec = (vec == 0), last_vec = (vec == nvec - 1);
-    const bool has_left = lane != 0, has_right = lane != 63;
+    const bool has_left = lane != 0, has_right = lane != 63;  // neighbour vector lives in the same wave
+
+    const bool multi_wave = (64 % nvec) != 0;  // some row crosses a wave boundary
+    // ---- x end cells cross waves through LDS (cheaper than two masked per-lane loads per position) ---------
+    if (XLDS && multi_wave) {
+#pragma unroll
+        for (int c = -1; c <= RK; ++c)
+#pragma unroll
+            for (int r = -1; r <= RJ; ++r) {
+                if (SF_DIST(c, RK) + SF_DIST(r, RJ) > 1) continue;
+                if (lane == 0) shx_first[wave][(c + 1) * (RJ + 2) + (r + 1)] = X[c + 2][r + 2][0];
+                if (lane == 63) shx_last[wave][(c + 1) * (RJ + 2) + (r + 1)] = X[c + 2][r + 2][W - 1];
+            }
+        __syncthreads();
+    }
 
     // ---- first sweep: y on the cross-shaped neighbourhood -------------------------------------------
     V Y[RK + 2][RJ + 2];
@@ -602,15 +625,16 @@ __global__ void __launch_bounds__(256, SF_J2_WAVES) jacobi2_kernel(Geom g, Jacob
             const T up = lane_up(cc[W - 1]);
             const T dn = lane_dn(cc[0]);
             const long q = planeq[c + 2] + rowq[r + 2];
+            const int pos = (c + 1) * (RJ + 2) + (r + 1);
             T xm, xp;
             if (first_vec)
                 xm = m.ishell_mem ? x[q - 1] : sx * cc[0];
             else
-                xm = has_left ? up : x[q - 1];
+                xm = has_left ? up : (XLDS ? shx_last[wave > 0 ? wave - 1 : 0][pos] : x[q - 1]);
             if (last_vec)
                 xp = m.ishell_mem ? x[q + W] : sx * cc[W - 1];
             else
-                xp = has_right ? dn : x[q + W];
+                xp = has_right ? dn : (XLDS ? shx_first[wave < 3 ? wave + 1 : 3][pos] : x[q + W]);
             const V km = X[c + 1][r + 2], kp = X[c + 3][r + 2];
             const V jm = X[c + 2][r + 1], jp = X[c + 2][r + 3];
             const V s = S[c + 1][r + 1];
@@ -625,7 +649,6 @@ __global__ void __launch_bounds__(256, SF_J2_WAVES) jacobi2_kernel(Geom g, Jacob
         }
 
     // ---- end cells of y cross waves through LDS (only when a row is wider than one wave) ---------------
-    const bool multi_wave = blockDim.x > 64;
     if (multi_wave) {
 #pragma unroll
         for (int rk = 0; rk < RK; ++rk)
