@@ -1005,6 +1005,150 @@ __global__ void __launch_bounds__(256) advect_kernel(Geom g, AdvectArgs<T, NF> A
     }
 }
 
+// LDS-staged advect (opt-in, SF_ADVECT_LDS=1; a measured NEGATIVE result kept for the record: 1.5x slower than
+// advect_kernel at 256^3). The gathers of advect_kernel are texture-address bound (12 two-wide gathers per cell and
+// field). Here a workgroup (one whole-row tile: tx = N/W lanes x ty rows of one plane) first stages, per field,
+// the rows jb-1 .. jb+ty of planes kl-1 .. kl+1 in LDS with coalesced 16-byte loads, then takes the eight
+// trilinear samples from LDS. That covers every back-trace of less than one cell (the benchmark's are <= 1/2);
+// if any cell of the tile reaches further the whole workgroup takes the global-memory path, so results never
+// depend on which path ran. Same expressions as advect_kernel: bit-identical.
+template <class T, int NF>
+__global__ void __launch_bounds__(256) advect_lds_kernel(Geom g, AdvectArgs<T, NF> A, int kb, int ke, TileMap m,
+                                                         int rs) {
+    constexpr int W = VecT<T>::W;
+    typedef typename VecT<T>::type V;
+    typedef T Pair __attribute__((ext_vector_type(2), aligned(sizeof(T))));
+    extern __shared__ __attribute__((aligned(16))) unsigned char sf_smem[];
+    T* __restrict__ tile = reinterpret_cast<T*>(sf_smem);  // [3][ty+2][rs], cell i of a row at index i + 3
+    int it, jt, kk, fdummy;
+    if (!flat_tile(m, ke - kb, it, jt, kk, fdummy)) return;  // uniform per workgroup
+    const int kl = plane_of(m, kb, kk);
+    const int N = g.N;
+    const int ty = (int)blockDim.y;
+    const int nvec = (N + W - 1) / W;
+    const int jb = 1 + jt * ty;
+    const int v = (int)threadIdx.x;
+    const int i0 = 1 + W * v;
+    const int j = jb + (int)threadIdx.y;
+    const bool cell_ok = (v < nvec) && (j <= N);
+    int nv = N - i0 + 1;
+    nv = nv > W ? W : (nv < 0 ? 0 : nv);
+    const T Nf = (T)N;
+    const T lo = T(0.5), hi = Nf + T(0.5);
+    const int kg = g.kg0 + kl;
+    const long q = row0(g, j <= N ? j : N, kl) + (v < nvec ? i0 : 1);
+
+    // ---- back-trace (shared by the NF fields) ------------------------------------------------------------
+    int ia[W], jr[W], kz[W], kla[W], jaa[W];
+    T s1[W], t1[W], r1[W];
+    bool near = true, bad = false;
+    {
+        V uu, vv, ww;
+        if (cell_ok) {
+            uu = ldv(A.u + q);
+            vv = ldv(A.v + q);
+            ww = ldv(A.w + q);
+        }
+#pragma unroll
+        for (int e = 0; e < W; ++e) {
+            ia[e] = 1; jr[e] = 1; kz[e] = 1; kla[e] = kl; jaa[e] = 1;
+            s1[e] = t1[e] = r1[e] = T(0);
+            if (!cell_ok || e >= nv) continue;
+            T x = (T)(i0 + e) - A.dt0 * uu[e];
+            T y = (T)j - A.dt0 * vv[e];
+            T z = (T)kg - A.dt0 * ww[e];
+            if (x < lo) x = lo;
+            if (x > hi) x = hi;
+            if (y < lo) y = lo;
+            if (y > hi) y = hi;
+            if (z < lo) z = lo;
+            if (z > hi) z = hi;
+            int a = (x == x) ? (int)x : 0;
+            int b = (y == y) ? (int)y : 0;
+            int c = (z == z) ? (int)z : 0;
+            a = a < 0 ? 0 : (a > N ? N : a);
+            b = b < 0 ? 0 : (b > N ? N : b);
+            c = c < 0 ? 0 : (c > N ? N : c);
+            s1[e] = x - (T)a;
+            t1[e] = y - (T)b;
+            r1[e] = z - (T)c;
+            int cl = c - g.kg0;
+            if (cl < 0 || cl > g.np - 2) {
+                bad = true;
+                cl = cl < 0 ? 0 : g.np - 2;
+            }
+            ia[e] = a;
+            jaa[e] = b;
+            kla[e] = cl;
+            jr[e] = b - (jb - 1);        // tile row of j0: rows 0 .. ty+1 hold jb-1 .. jb+ty
+            kz[e] = cl - (kl - 1);       // tile plane of k0: planes 0 .. 2 hold kl-1 .. kl+1
+            if (jr[e] < 0 || jr[e] > ty || kz[e] < 0 || kz[e] > 1) near = false;
+        }
+    }
+    if (bad) atomicOr(A.flag, 1);
+    const bool use_lds = __syncthreads_and(near ? 1 : 0) != 0;
+
+    T out[NF][W];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+        const T* __restrict__ d0 = A.d0[f];
+        if (use_lds) {
+            // stage planes kl-1..kl+1, rows jb-1..jb+ty (clamped into the stored range; clamped rows are never read)
+            const int nrows = 3 * (ty + 2);
+            for (int r0 = 0; r0 < nrows; r0 += ty) {
+                const int r = r0 + (int)threadIdx.y;
+                if (r < nrows && v < nvec) {
+                    const int pz = r / (ty + 2), pr = r - pz * (ty + 2);
+                    int jj = jb - 1 + pr;
+                    jj = jj > N + 1 ? N + 1 : jj;
+                    int kq = kl - 1 + pz;
+                    kq = kq < 0 ? 0 : (kq > g.np - 1 ? g.np - 1 : kq);
+                    const long src = row0(g, jj, kq);
+                    T* dst = tile + (long)r * rs + 3;
+                    *reinterpret_cast<V*>(dst + i0) = ldv(d0 + src + i0);  // cells i0 .. i0+W-1 (pads beyond N+1)
+                    if (v == 0) dst[0] = d0[src];
+                    if (v == nvec - 1 && i0 + W - 1 < N + 1) dst[N + 1] = d0[src + N + 1];
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < W; ++e) {
+                out[f][e] = T(0);
+                if (!cell_ok || e >= nv) continue;
+                const T s0 = T(1) - s1[e], t0 = T(1) - t1[e], r0w = T(1) - r1[e];
+                const T* p00 = tile + ((long)(kz[e] * (ty + 2) + jr[e])) * rs + 3 + ia[e];
+                const T* p01 = p00 + (long)(ty + 2) * rs;
+                const T* p10 = p00 + rs;
+                const T* p11 = p10 + (long)(ty + 2) * rs;
+                out[f][e] = s0 * (t0 * (r0w * p00[0] + r1[e] * p01[0]) + t1[e] * (r0w * p10[0] + r1[e] * p11[0])) +
+                            s1[e] * (t0 * (r0w * p00[1] + r1[e] * p01[1]) + t1[e] * (r0w * p10[1] + r1[e] * p11[1]));
+            }
+            __syncthreads();  // the tile is reused by the next field
+        } else {
+#pragma unroll
+            for (int e = 0; e < W; ++e) {
+                out[f][e] = T(0);
+                if (!cell_ok || e >= nv) continue;
+                const T s0 = T(1) - s1[e], t0 = T(1) - t1[e], r0w = T(1) - r1[e];
+                const long p00 = row0(g, jaa[e], kla[e]) + ia[e];
+                const long p01 = p00 + g.plane, p10 = p00 + g.px, p11 = p10 + g.plane;
+                const Pair c00 = *reinterpret_cast<const Pair*>(d0 + p00);
+                const Pair c01 = *reinterpret_cast<const Pair*>(d0 + p01);
+                const Pair c10 = *reinterpret_cast<const Pair*>(d0 + p10);
+                const Pair c11 = *reinterpret_cast<const Pair*>(d0 + p11);
+                out[f][e] = s0 * (t0 * (r0w * c00[0] + r1[e] * c01[0]) + t1[e] * (r0w * c10[0] + r1[e] * c11[0])) +
+                            s1[e] * (t0 * (r0w * c00[1] + r1[e] * c01[1]) + t1[e] * (r0w * c10[1] + r1[e] * c11[1]));
+            }
+        }
+    }
+    if (!cell_ok) return;
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+        store_cells<T, W>(A.d[f], q - i0, i0, out[f], nv);
+        emit_shells<T, W>(A.d[f], g, A.b[f], i0, j, kl, out[f], nv);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // project, first half: div = c_div*((du + dv) + dw), set_bnd(0, div). p is zeroed by the caller
 // (hipMemsetAsync over the whole field, which also covers set_bnd(0,p) and the ghost planes).

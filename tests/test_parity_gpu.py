@@ -146,6 +146,32 @@ def test_advect(N, b, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "f64"])
+@pytest.mark.parametrize("mode", ["near", "mixed"])
+@pytest.mark.parametrize("N,b", [(1, 0), (3, 1), (8, 2), (13, 3), (32, 1), (64, 0), (100, 2)])
+def test_advect_lds_path(N, b, mode, dtype, monkeypatch):
+    """(opt-in kernel, SF_ADVECT_LDS=1) Back-traces shorter than one cell take the LDS-staged path; 'mixed' puts a few long back-traces into some
+    tiles so both paths run in one launch. Either way the result must equal the oracle."""
+    monkeypatch.setenv("SF_ADVECT_LDS", "1")
+    rng = np.random.RandomState(60 + N)
+    f = rand_fields(N, dtype, 61)
+    lim = 0.95 / (DT * N)
+    for n in ("u", "v", "w"):
+        f[n] = rng.uniform(-lim, lim, size=f[n].shape).astype(dtype)
+    if mode == "mixed":
+        for n in ("u", "v", "w"):
+            idx = tuple(rng.randint(0, N + 2, size=(3, max(1, N // 2))))
+            f[n][idx] = dtype(rng.choice([-4.0, 3.0]))
+    with make(N, dtype) as fs:
+        for n in ("dens", "dens0", "u", "v", "w"):
+            fs.upload(n, f[n])
+        fs.advect(b, "dens", "dens0", "u", "v", "w")
+        got = fs.download("dens")
+    want = f["dens"].copy()
+    O.advect(b, want, f["dens0"], f["u"], f["v"], f["w"], dtype(DT))
+    assert_same(got, want, f"advect(lds,{mode}) b={b}")
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "f64"])
 @pytest.mark.parametrize("N,K", [(1, 2), (3, 3), (8, 4), (17, 5), (32, 6)])
 def test_project(N, K, dtype):
     f = rand_fields(N, dtype, 7)

@@ -6,6 +6,7 @@
 # Copy the summaries into profiles/ afterwards with tools/summarize_profiles.py.
 tag=${1:-r01}
 out=gpurun_out/profiles_$tag
+rm -rf $out
 mkdir -p $out
 export TMPDIR=/tmp
 python3 bench.py > $out/bench.json 2> $out/bench.err || exit 1
