@@ -520,3 +520,43 @@ def test_driver_frame_equals_config1_golden(tmp_path):
         data = open(tmp_path / "anim_s0.vtk", "rb").read()
         assert len(data) == gold[key]["bytes"]
         assert hashlib.sha256(data).hexdigest() == gold[key]["sha256"]
+
+
+def _random_cases(n, seed=1234):
+    rng = np.random.RandomState(seed)
+    out = []
+    for q in range(n):
+        N = int(rng.choice([1, 2, 3, 4, 6, 7, 8, 10, 12, 15, 16, 20, 24, 28, 33, 36, 40, 48, 52, 60, 64, 68, 72]))
+        divs = [d for d in range(1, N + 1) if N % d == 0 and d <= 12]
+        P = int(rng.choice(divs))
+        K = int(rng.randint(0, 8))
+        steps = int(rng.randint(1, 3))
+        dtype = np.float32 if rng.rand() < 0.6 else np.float64
+        out.append((N, P, K, steps, dtype, int(rng.randint(0, 10 ** 6))))
+    return out
+
+
+@pytest.mark.parametrize("case", _random_cases(36), ids=lambda c: f"N{c[0]}-P{c[1]}-K{c[2]}-s{c[3]}-{'f32' if c[4] == np.float32 else 'f64'}")
+def test_randomised_full_steps(case):
+    """Seeded random sweep over grid size, slab count, iteration count (incl. 0 and odd), steps and dtype."""
+    N, P, K, steps, dtype, seed = case
+    f = small_velocity(rand_fields(N, dtype, seed), N, dtype)
+    src = {n: f[n].copy() for n in ("u0", "v0", "w0", "dens0")}
+    with make(N, dtype, K=K, nslabs_local=P) as fs:
+        for n in NAMES:
+            fs.upload(n, f[n])
+        for s in range(steps):
+            if s > 0 and s % 2 == 1:
+                for n in src:
+                    fs.upload(n, src[n])
+            fs.vel_step()
+            fs.dens_step()
+        fs.sync()
+        got = {n: fs.download(n) for n in NAMES}
+    for s in range(steps):
+        if s > 0 and s % 2 == 1:
+            for n in src:
+                f[n][...] = src[n]
+        O.step(N, f, dtype(DT), dtype(DIFF), dtype(VISC), K)
+    for n in NAMES:
+        assert_same(got[n], f[n], f"{case[:4]}: {n}")
