@@ -209,6 +209,7 @@ public:
         kc2_ = env_int("SF_KC2", 32);
         f2_shape_ = env_int("SF_F2", 22);
         advect_lds_ = env_int("SF_ADVECT_LDS", 0) != 0;
+        zero_skip_ = env_int("SF_ZERO_SKIP", 1) != 0;
         tx_override_ = env_int("SF_TX", 0);
         SF_HIP(hipDeviceSynchronize());
     }
@@ -904,6 +905,18 @@ private:
         return fuse2_ && (P_ == 1 || G_ == 2) && N_ % W == 0 && N_ / W <= 128 && jacobi_mode_ != 0;
     }
 
+    template <int NF>
+    static sfk::JacobiArgs<T, 1> first_field(const sfk::JacobiArgs<T, NF>& A) {
+        sfk::JacobiArgs<T, 1> B;
+        B.x[0] = A.x[0];
+        B.x0[0] = A.x0[0];
+        B.xn[0] = A.xn[0];
+        B.b[0] = A.b[0];
+        B.a = A.a;
+        B.inv = A.inv;
+        return B;
+    }
+
     template <int NF, bool NT, int RJ, int RK>
     void launch_fused2(Slab& sl, const sfk::JacobiArgs<T, NF>& A, int kb, int ke, bool first, bool last) {
         const int nvec = N_ / W;
@@ -919,12 +932,21 @@ private:
         m.gap = gap_;
         const long per_plane = m.band > 0 ? (long)m.nxcd * m.band : (long)m.gy;
         const long nblocks = per_plane * ceil_div(ke - kb, RK) * NF;
-        if (nvec % 64 != 0 && 64 % nvec != 0)
+        const bool xlds = nvec % 64 != 0 && 64 % nvec != 0;
+        if (NF == 1 && x_is_zero_) {
+            if (xlds)
+                hipLaunchKernelGGL((sfk::jacobi2_kernel<T, 1, NT, RJ, RK, true, true>), dim3((unsigned)nblocks), dim3(256),
+                                   0, sl.cs, sl.geom, first_field(A), kb, ke, m);
+            else
+                hipLaunchKernelGGL((sfk::jacobi2_kernel<T, 1, NT, RJ, RK, false, true>), dim3((unsigned)nblocks), dim3(256),
+                                   0, sl.cs, sl.geom, first_field(A), kb, ke, m);
+        } else if (xlds) {
             hipLaunchKernelGGL((sfk::jacobi2_kernel<T, NF, NT, RJ, RK, true>), dim3((unsigned)nblocks), dim3(256), 0,
                                sl.cs, sl.geom, A, kb, ke, m);
-        else
+        } else {
             hipLaunchKernelGGL((sfk::jacobi2_kernel<T, NF, NT, RJ, RK, false>), dim3((unsigned)nblocks), dim3(256), 0,
                                sl.cs, sl.geom, A, kb, ke, m);
+        }
     }
 
     // LDS-staged marching form: rows of up to 128 vectors (blockDim = NV x 4 <= 512 threads).
@@ -977,7 +999,8 @@ private:
 
     // K Jacobi sweeps on NF fields at once; scratch buffers are swapped into the slots.
     template <int NF>
-    void op_lin_solve(const int (&x)[NF], const int (&x0)[NF], const int (&b)[NF], T a, T c, int K) {
+    void op_lin_solve(const int (&x)[NF], const int (&x0)[NF], const int (&b)[NF], T a, T c, int K,
+                      bool x_zero = false) {
         static_assert(NF <= NSCRATCH, "not enough scratch buffers");
         const T inv = T(1) / c;
         for (Slab& sl : slabs_)
@@ -989,6 +1012,7 @@ private:
         while (it < K) {
             const bool pair = can_fuse2() && it + 2 <= K;
             const int step = pair ? 2 : 1;
+            x_is_zero_ = x_zero && it == 0 && pair;  // the first fused pair then loads no x at all
             for_planes([&](Slab& sl, int kb, int ke) {
                 sfk::JacobiArgs<T, NF> A;
                 for (int f = 0; f < NF; ++f) {
@@ -1010,6 +1034,7 @@ private:
             exchange<NF>(x);
             it += step;
         }
+        x_is_zero_ = false;
     }
 
     template <int NF>
@@ -1067,9 +1092,12 @@ private:
             A.c_grad = T(0.5) * Nf;
             return A;
         };
+        // p = 0: when the first two sweeps are fused the kernel treats x as literal zeros and p is never read,
+        // so the fill (one word per cell) is skipped; otherwise zero the whole field (ghosts and shells included)
+        const bool implicit_zero = can_fuse2() && K_ >= 2 && zero_skip_;
         for (Slab& sl : slabs_) {
             ensure(sl, p);
-            SF_HIP(hipMemsetAsync(sl.field[p], 0, (size_t)field_elems_ * sizeof(T), sl.cs));
+            if (!implicit_zero) SF_HIP(hipMemsetAsync(sl.field[p], 0, (size_t)field_elems_ * sizeof(T), sl.cs));
         }
         for_planes([&](Slab& sl, int kb, int ke) {
             dim3 block;
@@ -1084,7 +1112,7 @@ private:
         const int dv[1] = {div};
         exchange<1>(dv);
         const int ps[1] = {p}, b0[1] = {0};
-        op_lin_solve<1>(ps, dv, b0, T(1), T(6), K_);
+        op_lin_solve<1>(ps, dv, b0, T(1), T(6), K_, implicit_zero);
         for_planes([&](Slab& sl, int kb, int ke) {
             dim3 block;
             unsigned nblocks;
@@ -1101,7 +1129,7 @@ private:
     T dt_{}, diff_{}, visc_{};
     int num_cu_ = 256;
     int nzl_ = 0, lead_ = 0, px_ = 0, nplanes_ = 0, kchunk_ = 0, jacobi_mode_ = 2, tx_override_ = 0, nt_mode_ = 2, rb_shape_ = 0;
-    bool ishell_skip_ = true, advect_lds_ = false;
+    bool ishell_skip_ = true, advect_lds_ = false, zero_skip_ = true, x_is_zero_ = false;
     int fuse2_ = 1, kc2_ = 32, f2_shape_ = 22;
     long plane_ = 0, field_elems_ = 0;
     std::vector<Slab> slabs_;

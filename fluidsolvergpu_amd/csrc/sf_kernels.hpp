@@ -501,7 +501,10 @@ __global__ void __launch_bounds__(256) jacobi_rb_kernel(Geom g, JacobiArgs<T, NF
 // XLDS: hand the x end cells across wave seams through LDS (one extra barrier) instead of masked per-lane loads.
 // Pays when rows start anywhere inside a wave (row width not a multiple of 64 vectors: both ends of most waves
 // are seams); with rows of 64 / 128 vectors each wave has at most one seam and the loads are cheaper.
-template <class T, int NF, bool NT, int RJ, int RK, bool XLDS>
+// XZ: the incoming iterate is identically zero (project's p = 0): no x is loaded at all — the same operations
+// are applied to literal zeros, so the bits equal a sweep over a zero-filled field — and the caller can skip the
+// memset of p.
+template <class T, int NF, bool NT, int RJ, int RK, bool XLDS, bool XZ = false>
 __global__ void __launch_bounds__(256, SF_J2_WAVES) jacobi2_kernel(Geom g, JacobiArgs<T, NF> A, int kb, int ke,
                                                        TileMap m) {
     constexpr int W = VecT<T>::W;
@@ -587,7 +590,14 @@ __global__ void __launch_bounds__(256, SF_J2_WAVES) jacobi2_kernel(Geom g, Jacob
     for (int c = -2; c <= RK + 1; ++c)
 #pragma unroll
         for (int r = -2; r <= RJ + 1; ++r)
-            if (SF_DIST(c, RK) + SF_DIST(r, RJ) <= 2) X[c + 2][r + 2] = ldv(x + planeq[c + 2] + rowq[r + 2]);
+            if (SF_DIST(c, RK) + SF_DIST(r, RJ) <= 2) {
+                if (XZ) {
+#pragma unroll
+                    for (int e = 0; e < W; ++e) X[c + 2][r + 2][e] = T(0);
+                } else {
+                    X[c + 2][r + 2] = ldv(x + planeq[c + 2] + rowq[r + 2]);
+                }
+            }
     V S[RK + 2][RJ + 2];
 #pragma unroll
     for (int c = -1; c <= RK; ++c)
@@ -602,7 +612,7 @@ __global__ void __launch_bounds__(256, SF_J2_WAVES) jacobi2_kernel(Geom g, Jacob
 
     const bool multi_wave = (64 % nvec) != 0;  // some row crosses a wave boundary
     // ---- x end cells cross waves through LDS (cheaper than two masked per-lane loads per position) ---------
-    if (XLDS && multi_wave) {
+    if (XLDS && !XZ && multi_wave) {
 #pragma unroll
         for (int c = -1; c <= RK; ++c)
 #pragma unroll
@@ -627,14 +637,19 @@ __global__ void __launch_bounds__(256, SF_J2_WAVES) jacobi2_kernel(Geom g, Jacob
             const long q = planeq[c + 2] + rowq[r + 2];
             const int pos = (c + 1) * (RJ + 2) + (r + 1);
             T xm, xp;
-            if (first_vec)
-                xm = m.ishell_mem ? x[q - 1] : sx * cc[0];
-            else
-                xm = has_left ? up : (XLDS ? shx_last[wave > 0 ? wave - 1 : 0][pos] : x[q - 1]);
-            if (last_vec)
-                xp = m.ishell_mem ? x[q + W] : sx * cc[W - 1];
-            else
-                xp = has_right ? dn : (XLDS ? shx_first[wave < 3 ? wave + 1 : 3][pos] : x[q + W]);
+            if (XZ) {
+                xm = T(0);
+                xp = T(0);
+            } else {
+                if (first_vec)
+                    xm = m.ishell_mem ? x[q - 1] : sx * cc[0];
+                else
+                    xm = has_left ? up : (XLDS ? shx_last[wave > 0 ? wave - 1 : 0][pos] : x[q - 1]);
+                if (last_vec)
+                    xp = m.ishell_mem ? x[q + W] : sx * cc[W - 1];
+                else
+                    xp = has_right ? dn : (XLDS ? shx_first[wave < 3 ? wave + 1 : 3][pos] : x[q + W]);
+            }
             const V km = X[c + 1][r + 2], kp = X[c + 3][r + 2];
             const V jm = X[c + 2][r + 1], jp = X[c + 2][r + 3];
             const V s = S[c + 1][r + 1];
