@@ -76,6 +76,7 @@ public:
     virtual void stored_planes(int* kb, int* ke) const = 0;
     virtual void fill(int field, double value) = 0;
     virtual void copy_field(int dst, int src) = 0;
+    virtual void bind_sources(int su, int sv, int sw, int sd) = 0;
     virtual void vel_step() = 0;
     virtual void dens_step() = 0;
     virtual void add_source(int x, int s) = 0;
@@ -422,11 +423,29 @@ public:
         op_project(u, v, w, p, div);
     }
 
+    void bind_sources(int su, int sv, int sw, int sd) override {
+        const int b[4] = {su, sv, sw, sd};
+        const int own[4] = {SF_U0, SF_V0, SF_W0, SF_DENS0};
+        for (int q = 0; q < 4; ++q) {
+            SF_REQUIRE(b[q] >= -1 && b[q] < SF_NUM_FIELDS, "bind_sources: slot out of range");
+            SF_REQUIRE(b[q] < 0 || b[q] >= SF_USER0, "bind_sources: sources must live in SF_USER0..3");
+            (void)own;
+        }
+        for (int q = 0; q < 4; ++q) bound_[q] = b[q];
+    }
+
     // SPEC §3 vel_step.
     void vel_step() override {
         SF_HIP(hipSetDevice(device_));
         const int vel[3] = {SF_U, SF_V, SF_W}, vel0[3] = {SF_U0, SF_V0, SF_W0}, b123[3] = {1, 2, 3};
-        op_add_source<3>(vel, vel0);
+        if (bound_[0] >= 0 && bound_[1] >= 0 && bound_[2] >= 0) {
+            const int src[3] = {bound_[0], bound_[1], bound_[2]};
+            op_add_source_bound<3>(vel, vel0, src);
+        } else {
+            for (int q = 0; q < 3; ++q)
+                if (bound_[q] >= 0) copy_field(vel0[q], bound_[q]);
+            op_add_source<3>(vel, vel0);
+        }
         swap_slots(SF_U0, SF_U);
         swap_slots(SF_V0, SF_V);
         swap_slots(SF_W0, SF_W);
@@ -444,7 +463,12 @@ public:
     void dens_step() override {
         SF_HIP(hipSetDevice(device_));
         const int x[1] = {SF_DENS}, x0[1] = {SF_DENS0}, b0[1] = {0};
-        op_add_source<1>(x, x0);
+        if (bound_[3] >= 0) {
+            const int src[1] = {bound_[3]};
+            op_add_source_bound<1>(x, x0, src);
+        } else {
+            op_add_source<1>(x, x0);
+        }
         swap_slots(SF_DENS0, SF_DENS);
         const T a = diffusion_a(diff_);
         op_lin_solve<1>(x, x0, b0, a, T(1) + T(6) * a, K_);
@@ -838,6 +862,23 @@ private:
         // ghosts of x and s were current, so the ghosts of the result are current: no exchange
     }
 
+    template <int NF>
+    void op_add_source_bound(const int (&x)[NF], const int (&s_copy)[NF], const int (&src)[NF]) {
+        const long nvec = field_elems_ / W;
+        for (Slab& sl : slabs_) {
+            sfk::AddSourceBoundArgs<T, NF> A;
+            for (int f = 0; f < NF; ++f) {
+                A.x[f] = ensure(sl, x[f]);
+                A.s_copy[f] = ensure(sl, s_copy[f]);
+                A.src[f] = ensure(sl, src[f]);
+            }
+            A.dt = dt_;
+            A.nvec = nvec;
+            hipLaunchKernelGGL((sfk::add_source_bound_kernel<T, NF>), dim3(stream_grid(nvec)), dim3(256), 0, sl.cs, A);
+        }
+        SF_HIP(hipGetLastError());
+    }
+
     // Jacobi sweep launcher. SF_JACOBI: 0 = k-marching kernel, 1 = register-blocked flat kernel, plain order,
     // 2 = the same with XCD bands (default). SF_NT: 0 never / 1 always / 2 auto non-temporal stores.
     // SF_ISHELL: 0 = always read+write the i-shell, 1 = recompute it in intermediate sweeps (default).
@@ -1125,6 +1166,7 @@ private:
 
     int N_, K_, device_;
     int L_ = 1, nranks_ = 1, rank_ = 0, P_ = 1, G_ = 1;
+    int bound_[4] = {-1, -1, -1, -1};  // resident source slots (sf_bind_sources)
     int split_ = INT_MAX, gap_ = 0;  // plane-range split of the launch being issued (for_planes)
     T dt_{}, diff_{}, visc_{};
     int num_cu_ = 256;
@@ -1251,6 +1293,9 @@ int sf_fill(sf_ctx* ctx, int field, double value) {
 }
 int sf_copy_field(sf_ctx* ctx, int dst, int src) {
     return guarded(ctx, [&](SolverBase& s) { s.copy_field(dst, src); });
+}
+int sf_bind_sources(sf_ctx* ctx, int su, int sv, int sw, int sd) {
+    return guarded(ctx, [&](SolverBase& s) { s.bind_sources(su, sv, sw, sd); });
 }
 int vel_step(sf_ctx* ctx) {
     return guarded(ctx, [&](SolverBase& s) { s.vel_step(); });

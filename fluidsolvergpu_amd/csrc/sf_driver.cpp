@@ -243,6 +243,7 @@ static int run(const Options& o) {
     SF_CHECK_RETURN(sf_upload(g_ctx, SF_USER1, in.sv.data()));
     SF_CHECK_RETURN(sf_upload(g_ctx, SF_USER2, in.sw.data()));
     SF_CHECK_RETURN(sf_upload(g_ctx, SF_USER3, in.sd.data()));
+    SF_CHECK_RETURN(sf_bind_sources(g_ctx, SF_USER0, SF_USER1, SF_USER2, SF_USER3));
 
     const size_t n = ((size_t)o.n + 2) * ((size_t)o.n + 2) * ((size_t)o.n + 2);
     std::vector<T> hd(n), hu(n), hv(n), hw(n);
@@ -287,11 +288,7 @@ static int run(const Options& o) {
         if (!o.quiet && talk) std::cout << "t= " << t << "\n";
         float elapsedTime = 0.f;
         SF_CHECK_RETURN(sf_timer_start(g_ctx));
-        SF_CHECK_RETURN(sf_copy_field(g_ctx, SF_U0, SF_USER0));
-        SF_CHECK_RETURN(sf_copy_field(g_ctx, SF_V0, SF_USER1));
-        SF_CHECK_RETURN(sf_copy_field(g_ctx, SF_W0, SF_USER2));
-        SF_CHECK_RETURN(sf_copy_field(g_ctx, SF_DENS0, SF_USER3));
-        SF_CHECK_RETURN(vel_step(g_ctx));
+        SF_CHECK_RETURN(vel_step(g_ctx));  // sources are bound (sf_bind_sources above)
         SF_CHECK_RETURN(dens_step(g_ctx));
         if (ntr > 0) SF_CHECK_RETURN(sf_tracers_advect(g_ctx));
         SF_CHECK_RETURN(sf_timer_stop(g_ctx, &elapsedTime));

@@ -215,6 +215,35 @@ __global__ void __launch_bounds__(256) add_source_kernel(AddSourceArgs<T, NF> A)
     }
 }
 
+// add_source with the source taken from a resident slot: x += dt*src and, in the same pass, s_copy = src, which
+// is exactly "copy src into the x0 slot, then add_source(x, x0)" (4 words per element instead of 5).
+template <class T, int NF>
+struct AddSourceBoundArgs {
+    T* x[NF];
+    T* s_copy[NF];
+    const T* src[NF];
+    T dt;
+    long nvec;
+};
+
+template <class T, int NF>
+__global__ void __launch_bounds__(256) add_source_bound_kernel(AddSourceBoundArgs<T, NF> A) {
+    constexpr int W = VecT<T>::W;
+    typedef typename VecT<T>::type V;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < A.nvec; q += stride) {
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+            V a = ldv(A.x[f] + q * W);
+            const V s = ldv(A.src[f] + q * W);
+#pragma unroll
+            for (int e = 0; e < W; ++e) a[e] = a[e] + A.dt * s[e];
+            stv(A.x[f] + q * W, a);
+            stv(A.s_copy[f] + q * W, s);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // lin_solve: one Jacobi sweep + fused set_bnd (SPEC §3 lin_solve). Algorithmic traffic 3 words
 // per cell (read x, read x0, write x'). Each thread owns a W-wide column piece and marches kchunk

@@ -30,7 +30,7 @@ ABI_SYMBOLS = (
     "dens_step", "sf_add_source", "sf_set_bnd", "sf_lin_solve", "sf_diffuse", "sf_advect", "sf_project",
     "sf_set_iters", "sf_set_coefficients", "sf_sync", "sf_last_error", "sf_timer_start", "sf_timer_stop",
     "sf_measure_copy_bandwidth", "sf_layout_info", "sf_lin_solve_launches", "sf_snapshot", "sf_snapshot_read",
-    "sf_tracers_set", "sf_tracers_advect", "sf_tracers_get",
+    "sf_tracers_set", "sf_tracers_advect", "sf_tracers_get", "sf_bind_sources",
 )
 
 
@@ -73,6 +73,7 @@ lib.sf_timer_start.argtypes = [_ctx]
 lib.sf_timer_stop.argtypes = [_ctx, C.POINTER(C.c_float)]
 lib.sf_measure_copy_bandwidth.argtypes = [_ctx, C.c_size_t, C.c_int, C.POINTER(C.c_double)]
 lib.sf_lin_solve_launches.argtypes = [_ctx, C.c_int]
+lib.sf_bind_sources.argtypes = [_ctx, C.c_int, C.c_int, C.c_int, C.c_int]
 lib.sf_snapshot.argtypes = [_ctx, C.POINTER(C.c_int), C.c_int]
 lib.sf_snapshot_read.argtypes = [_ctx, C.c_int, C.c_void_p]
 lib.sf_tracers_set.argtypes = [_ctx, C.c_int, C.c_void_p]
@@ -188,6 +189,10 @@ class FluidSolver:
 
     def copy_field(self, dst, src):
         self._ck(lib.sf_copy_field(self._h, _fid(dst), _fid(src)))
+
+    def bind_sources(self, su="user0", sv="user1", sw="user2", sd="user3"):
+        ids = [(-1 if f is None else _fid(f)) for f in (su, sv, sw, sd)]
+        self._ck(lib.sf_bind_sources(self._h, *ids))
 
     # -- the path --------------------------------------------------------------------------
     def vel_step(self):

@@ -104,6 +104,12 @@ int sf_copy_field(sf_ctx* ctx, int dst, int src);         /* dst <- src (device 
 int vel_step(sf_ctx* ctx);
 int dens_step(sf_ctx* ctx);
 
+/* Resident sources. After sf_bind_sources(ctx, su, sv, sw, sd) every vel_step / dens_step behaves exactly as if
+ * SF_U0, SF_V0, SF_W0 (vel_step) and SF_DENS0 (dens_step) had first been overwritten with copies of the bound
+ * slots (normally SF_USER0..3) — same bits, one pass less over memory than sf_copy_field + the step. Pass -1 for
+ * a source that stays "whatever is in the x0 slot"; sf_bind_sources(ctx, -1, -1, -1, -1) restores the default. */
+int sf_bind_sources(sf_ctx* ctx, int su, int sv, int sw, int sd);
+
 /* The operators of the path, exposed singly for parity tests and for timing the Jacobi sweep in
  * isolation. Field arguments are sf_field slots; `b` is the boundary mode 0..3. */
 int sf_add_source(sf_ctx* ctx, int x, int s);

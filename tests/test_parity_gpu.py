@@ -413,6 +413,32 @@ def test_snapshot_is_a_consistent_async_copy(P):
         assert_same(result[n], f[n], f"snapshot {n}")
 
 
+@pytest.mark.parametrize("P", [1, 2])
+def test_bound_sources(P):
+    """sf_bind_sources == copying the user slots into u0/v0/w0/dens0 before every step, bit for bit."""
+    N, dtype, K = 24, np.float32, 5
+    f = small_velocity(rand_fields(N, dtype, 70), N, dtype)
+    src = {"u0": f["u0"].copy(), "v0": f["v0"].copy(), "w0": f["w0"].copy(), "dens0": f["dens0"].copy()}
+    with make(N, dtype, K=K, nslabs_local=P) as fs:
+        for n in ("u", "v", "w", "dens"):
+            fs.upload(n, f[n])
+        for slot, n in (("user0", "u0"), ("user1", "v0"), ("user2", "w0"), ("user3", "dens0")):
+            fs.upload(slot, src[n])
+        fs.bind_sources("user0", "user1", "user2", "user3")
+        for _ in range(3):
+            fs.vel_step()
+            fs.dens_step()
+        fs.sync()
+        got = {n: fs.download(n) for n in NAMES}
+        assert_same(fs.download("user1"), src["v0"], "bound source slot must stay untouched")
+    for _ in range(3):
+        for n in src:
+            f[n][...] = src[n]
+        O.step(N, f, dtype(DT), dtype(DIFF), dtype(VISC), K)
+    for n in NAMES:
+        assert_same(got[n], f[n], f"bound sources P={P}: {n}")
+
+
 def test_invalid_arguments_are_rejected():
     Sx = S()
     with pytest.raises(Sx.SfError):
