@@ -586,3 +586,37 @@ def test_randomised_full_steps(case):
         O.step(N, f, dtype(DT), dtype(DIFF), dtype(VISC), K)
     for n in NAMES:
         assert_same(got[n], f[n], f"{case[:4]}: {n}")
+
+
+def test_hundred_steps_benchmark_inputs():
+    """BASELINE.json configs[1] shape at a size the oracle finishes in seconds: 100 steps of the benchmark inputs
+    (docs/SPEC.md §5) with bound sources, K = 20 — still bit-identical after 100 steps. For scale: the fp32 and fp64
+    oracles differ by 2.4e-7 (velocity) / 2.9e-5 (density) after 100 steps at 64^3 (tools/precision_report.py)."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import analytic_planes
+
+    N, K, dtype, steps = 48, 20, np.float32, 100
+    a = analytic_planes(N, 0, N + 2, DT, dtype)
+    f = {"u": a["u"], "v": a["v"], "w": a["w"], "dens": a["dens"]}
+    for b, n in ((1, "u"), (2, "v"), (3, "w"), (0, "dens")):
+        O.set_bnd(b, f[n])
+    with make(N, dtype, K=K) as fs:
+        for n in ("u", "v", "w", "dens"):
+            fs.upload(n, f[n])
+        for slot, n in (("user0", "su"), ("user1", "sv"), ("user2", "sw"), ("user3", "sd")):
+            fs.upload(slot, a[n])
+        fs.bind_sources("user0", "user1", "user2", "user3")
+        for _ in range(steps):
+            fs.vel_step()
+            fs.dens_step()
+        fs.sync()
+        got = {n: fs.download(n) for n in ("u", "v", "w", "dens")}
+    for _ in range(steps):
+        f.update({"u0": a["su"].copy(), "v0": a["sv"].copy(), "w0": a["sw"].copy(), "dens0": a["sd"].copy()})
+        O.step(N, f, dtype(DT), dtype(DIFF), dtype(VISC), K)
+    for n in got:
+        assert_same(got[n], f[n], f"100 steps: {n}")
+    assert np.isfinite(got["dens"]).all() and got["dens"].max() > 1.0
