@@ -211,6 +211,7 @@ public:
         f2_shape_ = env_int("SF_F2", 22);
         advect_lds_ = env_int("SF_ADVECT_LDS", 0) != 0;
         zero_skip_ = env_int("SF_ZERO_SKIP", 1) != 0;
+        fuse_maxvec_ = env_int("SF_FUSE_MAXVEC", 128);
         tx_override_ = env_int("SF_TX", 0);
         SF_HIP(hipDeviceSynchronize());
     }
@@ -943,7 +944,7 @@ private:
     // vector width and the grid is not decomposed (a second ghost plane would be needed).
     // (measured: +5 % at 512^3, +12 % at 256^3, -8 % at 1024^3 where a row spans four waves -> rows <= 128 vectors)
     bool can_fuse2() const {
-        return fuse2_ && (P_ == 1 || G_ == 2) && N_ % W == 0 && N_ / W <= 128 && jacobi_mode_ != 0;
+        return fuse2_ && (P_ == 1 || G_ == 2) && N_ % W == 0 && N_ / W <= fuse_maxvec_ && jacobi_mode_ != 0;
     }
 
     template <int NF>
@@ -1166,6 +1167,7 @@ private:
 
     int N_, K_, device_;
     int L_ = 1, nranks_ = 1, rank_ = 0, P_ = 1, G_ = 1;
+    int fuse_maxvec_ = 128;
     int bound_[4] = {-1, -1, -1, -1};  // resident source slots (sf_bind_sources)
     int split_ = INT_MAX, gap_ = 0;  // plane-range split of the launch being issued (for_planes)
     T dt_{}, diff_{}, visc_{};
