@@ -726,7 +726,7 @@ private:
         const int tx = nvec <= 256 ? nvec : 64;
         const int ty = std::max(1, 256 / tx);
         block = dim3(tx, ty, 1);
-        sfk::TileMap m;
+        sfk::TileMap m{};
         m.rows = 0;
         m.gx = ceil_div(nvec, tx);
         m.gy = ceil_div(N_, ty);
@@ -891,7 +891,7 @@ private:
         const int txmax = tx_override_ > 0 ? tx_override_ : 64;
         while (tx < nvec && tx < txmax) tx <<= 1;
         const int ty = 256 / tx;
-        sfk::TileMap m;
+        sfk::TileMap m{};
         m.gx = ceil_div(nvec, tx);
         m.gy = ceil_div(N_, ty * RJ);
         m.nxcd = 8;
@@ -962,7 +962,7 @@ private:
     template <int NF, bool NT, int RJ, int RK>
     void launch_fused2(Slab& sl, const sfk::JacobiArgs<T, NF>& A, int kb, int ke, bool first, bool last) {
         const int nvec = N_ / W;
-        sfk::TileMap m;
+        sfk::TileMap m{};
         m.rows = std::max(1, 256 / nvec);  // row strips per 256-thread workgroup
         m.gx = 1;
         m.gy = ceil_div(N_, m.rows * RJ);
@@ -999,7 +999,7 @@ private:
         constexpr int TJ = 8;
         const int nvec = N_ / W;
         const int NV = ceil_div(nvec, 64) * 64;
-        sfk::TileMap m;
+        sfk::TileMap m{};
         m.gx = 1;
         m.gy = ceil_div(N_, TJ);
         m.nxcd = 8;
