@@ -151,8 +151,12 @@ public:
         const int line = 128 / (int)sizeof(T);
         px_ = ceil_div(lead_ + N_ + 1 + W, line) * line;
         plane_ = (long)px_ * (N_ + 2);
-        // two ghost planes per side let sweep pairs be fused across slab boundaries (one exchange per pair)
-        G_ = (P_ > 1 && nzl_ >= 2 && env_int("SF_GHOST", 2) >= 2) ? 2 : 1;
+        // two ghost planes per side let sweep pairs be fused across slab boundaries (one exchange per pair); grids
+        // the fused kernel does not take (rows wider than 128 vectors, N not a multiple of W) keep one ghost plane
+        // and exchange one plane per sweep
+        const bool fusable = env_int("SF_FUSE2", 1) != 0 && env_int("SF_JACOBI", 2) != 0 && N_ % W == 0 &&
+                             N_ / W <= env_int("SF_FUSE_MAXVEC", 128);
+        G_ = (P_ > 1 && nzl_ >= 2 && fusable && env_int("SF_GHOST", 2) >= 2) ? 2 : 1;
         nplanes_ = nzl_ + 2 * G_;
         field_elems_ = plane_ * nplanes_ + 256;  // slack so whole-vector accesses never leave the buffer
         field_elems_ = (field_elems_ + W - 1) / W * W;
