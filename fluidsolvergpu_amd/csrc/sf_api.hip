@@ -113,8 +113,11 @@ class Solver final : public SolverBase {
         T* snap[4] = {};               // snapshot buffers for asynchronous output
         hipStream_t os = nullptr;      // output (copy) stream
         hipEvent_t snap_done = nullptr;
-        hipStream_t cs = nullptr;  // compute
-        hipStream_t hs = nullptr;  // halo
+        hipStream_t cs = nullptr;   // compute (interior planes, whole-field operators)
+        hipStream_t bs = nullptr;   // boundary planes of a decomposed grid: runs beside the interior launch
+        hipStream_t hs = nullptr;   // halo
+        hipStream_t cur = nullptr;  // where the launch being issued goes (cs or bs)
+        hipEvent_t cs_mark = nullptr;
         hipEvent_t boundary_done = nullptr;
         hipEvent_t halo_done = nullptr;
         int* d_flag = nullptr;
@@ -176,6 +179,9 @@ public:
             sl.geom.wall_lo = (sl.gid == 0);
             sl.geom.wall_hi = (sl.gid == P_ - 1);
             SF_HIP(hipStreamCreateWithFlags(&sl.cs, hipStreamNonBlocking));
+            SF_HIP(hipStreamCreateWithFlags(&sl.bs, hipStreamNonBlocking));
+            SF_HIP(hipEventCreateWithFlags(&sl.cs_mark, hipEventDisableTiming));
+            sl.cur = sl.cs;
             {
                 // SF_HALO_PRIO=1 gives the halo stream the highest priority so its traffic does not queue behind the
                 // interior sweep. Off by default: with logical slabs on ONE GPU it doubles the step time (the copy
@@ -235,6 +241,8 @@ public:
             if (sl.os) (void)hipStreamDestroy(sl.os);
             if (sl.snap_done) (void)hipEventDestroy(sl.snap_done);
             if (sl.cs) (void)hipStreamDestroy(sl.cs);
+            if (sl.bs) (void)hipStreamDestroy(sl.bs);
+            if (sl.cs_mark) (void)hipEventDestroy(sl.cs_mark);
             if (sl.hs) (void)hipStreamDestroy(sl.hs);
             if (sl.boundary_done) (void)hipEventDestroy(sl.boundary_done);
             if (sl.halo_done) (void)hipEventDestroy(sl.halo_done);
@@ -250,6 +258,7 @@ public:
 
     // ---- host <-> device ------------------------------------------------------------------
     void upload(int field, const void* host) override {
+        join();
         check_field(field);
         SF_REQUIRE(host != nullptr, "null host pointer");
         SF_HIP(hipSetDevice(device_));
@@ -266,6 +275,7 @@ public:
     }
 
     void download(int field, void* host) override {
+        join();
         check_field(field);
         SF_REQUIRE(host != nullptr, "null host pointer");
         for (Slab& sl : slabs_) {
@@ -278,6 +288,7 @@ public:
     }
 
     void download_planes(int field, int kb, int ke, void* host) override {
+        join();
         check_field(field);
         SF_REQUIRE(host != nullptr, "null host pointer");
         SF_REQUIRE(kb < ke, "empty plane range");
@@ -297,6 +308,7 @@ public:
     }
 
     void upload_planes(int field, int kb, int ke, const void* host) override {
+        join();
         check_field(field);
         SF_REQUIRE(host != nullptr, "null host pointer");
         SF_REQUIRE(kb < ke, "empty plane range");
@@ -329,6 +341,7 @@ public:
     }
 
     void fill(int field, double value) override {
+        join();
         check_field(field);
         SF_HIP(hipSetDevice(device_));
         for (Slab& sl : slabs_) {
@@ -341,6 +354,7 @@ public:
     }
 
     void copy_field(int dst, int src) override {
+        join();
         check_field(dst);
         check_field(src);
         SF_REQUIRE(dst != src, "copy_field: dst == src");
@@ -362,6 +376,7 @@ public:
     }
 
     void set_bnd(int b, int x) override {
+        join();
         check_field(x);
         check_b(b);
         SF_HIP(hipSetDevice(device_));
@@ -492,9 +507,11 @@ public:
     }
 
     void sync() override {
+        join();
         SF_HIP(hipSetDevice(device_));
         for (Slab& sl : slabs_) {
             SF_HIP(hipStreamSynchronize(sl.cs));
+            SF_HIP(hipStreamSynchronize(sl.bs));
             SF_HIP(hipStreamSynchronize(sl.hs));
         }
         if (P_ > 1) {
@@ -516,10 +533,12 @@ public:
     }
 
     void timer_start() override {
+        join();
         SF_HIP(hipSetDevice(device_));
         SF_HIP(hipEventRecord(t0_, slabs_[0].cs));
     }
     float timer_stop() override {
+        join();
         SF_HIP(hipEventRecord(t1_, slabs_[0].cs));
         SF_HIP(hipEventSynchronize(t1_));
         float ms = 0.f;
@@ -528,6 +547,7 @@ public:
     }
 
     double copy_bandwidth(size_t bytes, int reps) override {
+        join();
         SF_HIP(hipSetDevice(device_));
         bytes = (bytes + 4095) / 4096 * 4096;
         if (copy_bytes_ != bytes) {
@@ -562,6 +582,7 @@ public:
 
     // ---- asynchronous output -----------------------------------------------------------------
     void snapshot(const int* fields, int nfields) override {
+        join();
         SF_REQUIRE(fields != nullptr && nfields >= 1 && nfields <= 4, "snapshot takes 1..4 fields");
         SF_HIP(hipSetDevice(device_));
         for (int q = 0; q < nfields; ++q) check_field(fields[q]);
@@ -598,6 +619,7 @@ public:
 
     // ---- tracers (SPEC §6) ----------------------------------------------------------------------
     void tracers_set(int n, const void* xyz) override {
+        join();
         SF_REQUIRE(P_ == 1, "tracers need a single-slab context");
         SF_REQUIRE(n >= 0 && (n == 0 || xyz != nullptr), "bad tracer array");
         SF_HIP(hipSetDevice(device_));
@@ -614,6 +636,7 @@ public:
         SF_HIP(hipStreamSynchronize(slabs_[0].cs));
     }
     void tracers_advect() override {
+        join();
         SF_REQUIRE(P_ == 1, "tracers need a single-slab context");
         if (tr_n_ == 0) return;
         SF_HIP(hipSetDevice(device_));
@@ -623,6 +646,7 @@ public:
         SF_HIP(hipGetLastError());
     }
     void tracers_get(void* xyz, void* dens, void* speed) override {
+        join();
         SF_REQUIRE(P_ == 1, "tracers need a single-slab context");
         if (tr_n_ == 0) return;
         SF_HIP(hipSetDevice(device_));
@@ -748,37 +772,66 @@ private:
     // Runs `launch(slab, kb, ke)` over the interior planes of every slab. With P > 1 the two
     // slab-boundary planes go first, their completion is recorded, and the rest follows so that the
     // halo exchange issued by the caller overlaps the interior work.
+    // Streams of a decomposed grid (P > 1). Per operator and slab:
+    //   bs: boundary launch B (first / last G interior planes; needs the previous halo and everything issued so far)
+    //   cs: interior launch I (needs the previous B and I, never a halo — its stencil stays inside the slab)
+    //   hs: halo exchange of B's planes, concurrent with I
+    // so a pair costs max(I, B + exchange) instead of B + max(I, exchange). Whole-field operators run on cs after
+    // join(), which makes cs wait for the last B and the last halo.
+    void join() {
+        if (P_ == 1 || !pending_join_) return;
+        for (int s = 0; s < L_; ++s) {
+            Slab& sl = slabs_[s];
+            SF_HIP(hipStreamWaitEvent(sl.cs, sl.boundary_done, 0));
+            SF_HIP(hipStreamWaitEvent(sl.cs, sl.halo_done, 0));
+            if (s > 0) SF_HIP(hipStreamWaitEvent(sl.cs, slabs_[s - 1].halo_done, 0));
+            if (s < L_ - 1) SF_HIP(hipStreamWaitEvent(sl.cs, slabs_[s + 1].halo_done, 0));
+        }
+        pending_join_ = false;
+    }
+
     template <class F>
-    void for_planes(F launch, int depth = 1, bool can_split = true) {
+    void for_planes(F launch, int depth = 1, bool can_split = true, bool interior_reads_ghosts = false) {
         // the exchange that follows ships G_ planes per side, so at least G_ planes per side must come out of
         // the boundary launch (whose completion the halo stream waits for), not out of the interior launch
         depth = std::max(depth, G_);
         const int kb = G_, ke = G_ + nzl_;
         if (P_ == 1) {
+            slabs_[0].cur = slabs_[0].cs;
             launch(slabs_[0], kb, ke);
             SF_HIP(hipGetLastError());
             return;
         }
+        const bool two_streams = can_split && nzl_ > 2 * depth && env_int("SF_SPLIT", 1) != 0 && !interior_reads_ghosts;
+        if (!two_streams) join();
         for (Slab& sl : slabs_) {
-            if (nzl_ <= 2 * depth) {
-                launch(sl, kb, ke);
-                SF_HIP(hipEventRecord(sl.boundary_done, sl.cs));
-            } else if (!can_split || !env_int("SF_SPLIT", 1)) {
-                launch(sl, kb, kb + depth);
-                launch(sl, ke - depth, ke);
-                SF_HIP(hipEventRecord(sl.boundary_done, sl.cs));
-                launch(sl, kb + depth, ke - depth);
-            } else {
-                // ONE launch over the first and the last `depth` interior planes (split plane range), then the
-                // interior, which overlaps the halo exchange the caller issues next
-                split_ = depth;
-                gap_ = nzl_ - 2 * depth;
-                launch(sl, kb, kb + 2 * depth);
-                split_ = INT_MAX;
-                gap_ = 0;
-                SF_HIP(hipEventRecord(sl.boundary_done, sl.cs));
-                launch(sl, kb + depth, ke - depth);
+            if (!two_streams) {
+                sl.cur = sl.cs;
+                if (nzl_ <= 2 * depth) {
+                    launch(sl, kb, ke);
+                    SF_HIP(hipEventRecord(sl.boundary_done, sl.cs));
+                } else {
+                    launch(sl, kb, kb + depth);
+                    launch(sl, ke - depth, ke);
+                    SF_HIP(hipEventRecord(sl.boundary_done, sl.cs));
+                    launch(sl, kb + depth, ke - depth);
+                }
+                continue;
             }
+            // I of this operator reads what the previous B wrote; B reads everything issued on cs so far
+            SF_HIP(hipStreamWaitEvent(sl.cs, sl.boundary_done, 0));
+            SF_HIP(hipEventRecord(sl.cs_mark, sl.cs));
+            SF_HIP(hipStreamWaitEvent(sl.bs, sl.cs_mark, 0));
+            // ONE launch over the first and the last `depth` interior planes (split plane range)
+            sl.cur = sl.bs;
+            split_ = depth;
+            gap_ = nzl_ - 2 * depth;
+            launch(sl, kb, kb + 2 * depth);
+            split_ = INT_MAX;
+            gap_ = 0;
+            SF_HIP(hipEventRecord(sl.boundary_done, sl.bs));
+            sl.cur = sl.cs;
+            launch(sl, kb + depth, ke - depth);
         }
         SF_HIP(hipGetLastError());
     }
@@ -840,18 +893,21 @@ private:
             }
             SF_HIP(hipEventRecord(sl.halo_done, sl.hs));
         }
-        // consumers: my own ghosts, and neighbours that pulled from my planes must be done before I
-        // overwrite them two sweeps later
+        // consumers: the next boundary launch reads my ghosts, and neighbours that pulled from my planes must be
+        // done before I overwrite them two sweeps later. The compute stream only waits when it runs a
+        // whole-field operator (join()).
         for (int s = 0; s < L_; ++s) {
             Slab& sl = slabs_[s];
-            SF_HIP(hipStreamWaitEvent(sl.cs, sl.halo_done, 0));
-            if (s > 0) SF_HIP(hipStreamWaitEvent(sl.cs, slabs_[s - 1].halo_done, 0));
-            if (s < L_ - 1) SF_HIP(hipStreamWaitEvent(sl.cs, slabs_[s + 1].halo_done, 0));
+            SF_HIP(hipStreamWaitEvent(sl.bs, sl.halo_done, 0));
+            if (s > 0) SF_HIP(hipStreamWaitEvent(sl.bs, slabs_[s - 1].halo_done, 0));
+            if (s < L_ - 1) SF_HIP(hipStreamWaitEvent(sl.bs, slabs_[s + 1].halo_done, 0));
         }
+        pending_join_ = true;
     }
 
     template <int NF>
     void op_add_source(const int (&x)[NF], const int (&s)[NF]) {
+        join();
         const long nvec = field_elems_ / W;
         for (Slab& sl : slabs_) {
             sfk::AddSourceArgs<T, NF> A;
@@ -869,6 +925,7 @@ private:
 
     template <int NF>
     void op_add_source_bound(const int (&x)[NF], const int (&s_copy)[NF], const int (&src)[NF]) {
+        join();
         const long nvec = field_elems_ / W;
         for (Slab& sl : slabs_) {
             sfk::AddSourceBoundArgs<T, NF> A;
@@ -907,7 +964,7 @@ private:
         const long per_plane = m.band > 0 ? (long)m.nxcd * m.gx * m.band : (long)m.gx * m.gy;
         const long nblocks = per_plane * ceil_div(ke - kb, RK) * NF;
         hipLaunchKernelGGL((sfk::jacobi_rb_kernel<T, NF, NT, RJ, RK>), dim3((unsigned)nblocks), dim3(tx, ty), 0,
-                           sl.cs, sl.geom, A, kb, ke, m);
+                           sl.cur, sl.geom, A, kb, ke, m);
     }
 
     template <int NF, bool NT>
@@ -932,7 +989,7 @@ private:
     void launch_jacobi(Slab& sl, const sfk::JacobiArgs<T, NF>& A, int kb, int ke, bool first, bool last) {
         if (jacobi_mode_ == 0) {
             const Tile t = tile(ke - kb, true);
-            hipLaunchKernelGGL((sfk::jacobi_kernel<T, NF>), t.grid, t.block, 0, sl.cs, sl.geom, A, kb, ke, t.kchunk);
+            hipLaunchKernelGGL((sfk::jacobi_kernel<T, NF>), t.grid, t.block, 0, sl.cur, sl.geom, A, kb, ke, t.kchunk);
             return;
         }
         // non-temporal stores pay once x, x0 and x' of all NF fields no longer fit the 256 MiB Infinity Cache
@@ -982,16 +1039,16 @@ private:
         if (NF == 1 && x_is_zero_) {
             if (xlds)
                 hipLaunchKernelGGL((sfk::jacobi2_kernel<T, 1, NT, RJ, RK, true, true>), dim3((unsigned)nblocks), dim3(256),
-                                   0, sl.cs, sl.geom, first_field(A), kb, ke, m);
+                                   0, sl.cur, sl.geom, first_field(A), kb, ke, m);
             else
                 hipLaunchKernelGGL((sfk::jacobi2_kernel<T, 1, NT, RJ, RK, false, true>), dim3((unsigned)nblocks), dim3(256),
-                                   0, sl.cs, sl.geom, first_field(A), kb, ke, m);
+                                   0, sl.cur, sl.geom, first_field(A), kb, ke, m);
         } else if (xlds) {
             hipLaunchKernelGGL((sfk::jacobi2_kernel<T, NF, NT, RJ, RK, true>), dim3((unsigned)nblocks), dim3(256), 0,
-                               sl.cs, sl.geom, A, kb, ke, m);
+                               sl.cur, sl.geom, A, kb, ke, m);
         } else {
             hipLaunchKernelGGL((sfk::jacobi2_kernel<T, NF, NT, RJ, RK, false>), dim3((unsigned)nblocks), dim3(256), 0,
-                               sl.cs, sl.geom, A, kb, ke, m);
+                               sl.cur, sl.geom, A, kb, ke, m);
         }
     }
 
@@ -1016,7 +1073,7 @@ private:
         const long per_plane = m.band > 0 ? (long)m.nxcd * m.band : (long)m.gy;
         const long nblocks = per_plane * ceil_div(ke - kb, kc) * NF;
         const size_t lds = (size_t)2 * (TJ + 4) * NV * sizeof(typename sfk::VecT<T>::type);
-        hipLaunchKernelGGL((sfk::jacobi2m_kernel<T, NF, NT, TJ>), dim3((unsigned)nblocks), dim3(NV, 4), lds, sl.cs,
+        hipLaunchKernelGGL((sfk::jacobi2m_kernel<T, NF, NT, TJ>), dim3((unsigned)nblocks), dim3(NV, 4), lds, sl.cur,
                            sl.geom, A, kb, ke, m, kc);
     }
 
@@ -1116,11 +1173,11 @@ private:
             const int rs = 4 + 4 * ceil_div(N_ + 2 + W, 4) + 4;  // tile row stride, elements
             const size_t lds = (size_t)3 * (block.y + 2) * rs * sizeof(T);
             if (advect_lds_ && m.gx == 1 && lds <= 64 * 1024)
-                hipLaunchKernelGGL((sfk::advect_lds_kernel<T, NF>), dim3(nblocks), block, lds, sl.cs, sl.geom, A, kb,
+                hipLaunchKernelGGL((sfk::advect_lds_kernel<T, NF>), dim3(nblocks), block, lds, sl.cur, sl.geom, A, kb,
                                    ke, m, rs);
             else
-                hipLaunchKernelGGL((sfk::advect_kernel<T, NF>), dim3(nblocks), block, 0, sl.cs, sl.geom, A, kb, ke, m);
-        });
+                hipLaunchKernelGGL((sfk::advect_kernel<T, NF>), dim3(nblocks), block, 0, sl.cur, sl.geom, A, kb, ke, m);
+        }, 1, true, /*interior_reads_ghosts=*/true);  // a long back-trace may reach a ghost plane from any plane
         exchange<NF>(d);
     }
 
@@ -1141,6 +1198,7 @@ private:
         // p = 0: when the first two sweeps are fused the kernel treats x as literal zeros and p is never read,
         // so the fill (one word per cell) is skipped; otherwise zero the whole field (ghosts and shells included)
         const bool implicit_zero = can_fuse2() && K_ >= 2 && zero_skip_;
+        if (!implicit_zero) join();
         for (Slab& sl : slabs_) {
             ensure(sl, p);
             if (!implicit_zero) SF_HIP(hipMemsetAsync(sl.field[p], 0, (size_t)field_elems_ * sizeof(T), sl.cs));
@@ -1149,7 +1207,7 @@ private:
             dim3 block;
             unsigned nblocks;
             const sfk::TileMap m = flat_map(ke - kb, block, nblocks);
-            hipLaunchKernelGGL((sfk::project_div_kernel<T>), dim3(nblocks), block, 0, sl.cs, sl.geom, args(sl), kb, ke, m);
+            hipLaunchKernelGGL((sfk::project_div_kernel<T>), dim3(nblocks), block, 0, sl.cur, sl.geom, args(sl), kb, ke, m);
         });
         // div's ghost planes are exchanged although a single sweep reads div at cell centres only: the fused
         // sweep pair evaluates its first sweep on the first ghost plane and needs x0 = div there, and div is left
@@ -1163,7 +1221,7 @@ private:
             dim3 block;
             unsigned nblocks;
             const sfk::TileMap m = flat_map(ke - kb, block, nblocks);
-            hipLaunchKernelGGL((sfk::project_sub_kernel<T>), dim3(nblocks), block, 0, sl.cs, sl.geom, args(sl), kb, ke, m);
+            hipLaunchKernelGGL((sfk::project_sub_kernel<T>), dim3(nblocks), block, 0, sl.cur, sl.geom, args(sl), kb, ke, m);
         });
         const int uvw[3] = {u, v, w};
         exchange<3>(uvw);
@@ -1173,6 +1231,7 @@ private:
     int L_ = 1, nranks_ = 1, rank_ = 0, P_ = 1, G_ = 1;
     int fuse_maxvec_ = 128;
     int bound_[4] = {-1, -1, -1, -1};  // resident source slots (sf_bind_sources)
+    bool pending_join_ = false;
     int split_ = INT_MAX, gap_ = 0;  // plane-range split of the launch being issued (for_planes)
     T dt_{}, diff_{}, visc_{};
     int num_cu_ = 256;
