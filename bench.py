@@ -143,7 +143,13 @@ def main():
     if "SF_FORCE_DEVICE" in os.environ:  # rehearsal of the multi-rank path on a one-GPU box
         local_rank = int(os.environ["SF_FORCE_DEVICE"])
     dist = sfdist.init("gloo")  # control plane only; the halo exchange is RCCL inside libsfgpu.so
-    from fluidsolvergpu_amd import solver as S
+    if os.environ.get("SF_BENCH_DRYRUN") == "1":
+        # CPU-only rehearsal of THIS FILE's multi-rank plumbing (tests/test_dist_gloo.py): a stand-in with the same
+        # method names that computes nothing. Never used for a reported number: the output is tagged "dryrun".
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import bench_dryrun_stub as S
+    else:
+        from fluidsolvergpu_amd import solver as S
 
     K, dt, diff, visc = args.iters, 0.1, 1e-4, 1e-4
     N = args.n if args.n > 0 else WEAK_GRID.get(world, 256 * world)
@@ -211,7 +217,8 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": args.dtype,
-            "data": "synthetic (analytic fields of docs/SPEC.md §5, resident in HBM)",
+            "data": ("DRYRUN - no computation" if os.environ.get("SF_BENCH_DRYRUN") == "1"
+                     else "synthetic (analytic fields of docs/SPEC.md §5, resident in HBM)"),
             "config": {"workload": f"{N}^3 {args.dtype}, K={K} Jacobi iters per lin_solve, vel_step+dens_step "
                                    f"with per-step source re-injection", "grid": N, "jacobi_iters": K,
                        "slabs": world * args.local_slabs, "cells_per_gpu": cells / world,

@@ -43,3 +43,27 @@ def test_partition_arithmetic():
     assert seen == list(range(1, N + 1))
     with pytest.raises(ValueError):
         d.slab_planes(10, 0, 3)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_bench_multirank_plumbing_dryrun(world):
+    """bench.py --gpus N exactly as the driver launches it, with the solver replaced by a stub (SF_BENCH_DRYRUN=1):
+    rank 0 must print ONE JSON line with the contract fields, n_gpus == N, weak-scaling grid, tagged as a dry run."""
+    import json
+
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, OMP_NUM_THREADS="1", SF_BENCH_DRYRUN="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.join(root, "bench.py"),
+           "--gpus", str(world), "--steps", "2", "--warmup", "1", "--grid", str(8 * world)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in d, key
+    assert d["n_gpus"] == world and d["steps"] == 2 and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["data"].startswith("DRYRUN") and "workload" in d["config"]
+    assert "cpu_baseline" not in d  # only reported at N = 1
