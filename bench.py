@@ -261,4 +261,16 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except SystemExit:
+        raise
+    except BaseException as exc:  # report the failure in the contract's shape instead of dying silently
+        import traceback
+
+        traceback.print_exc()
+        if int(os.environ.get("RANK", "0")) == 0:
+            print(json.dumps({"metric": "Mcells/s per vel_step+dens_step", "value": None, "unit": "Mcells/s",
+                              "n_gpus": int(os.environ.get("WORLD_SIZE", "1")), "higher_is_better": True,
+                              "error": f"{type(exc).__name__}: {exc}"[:500]}), flush=True)
+        sys.exit(1)
