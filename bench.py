@@ -108,10 +108,25 @@ def time_lin_solve(S, N, dtype, K, reps, device):
 
 
 def cpu_baseline(N, K, dtype, steps, dt, diff, visc):
+    """Serial CPU oracle on this box's host cores (1 thread). Up to 256^3: `steps` full vel_step+dens_step on the
+    benchmark inputs. Larger grids: one lin_solve of K Jacobi iterations only, reported in the same
+    unit through the step's algorithmic cost ((56+18K) words per cell per step vs 3K per lin_solve)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
 
     npdt = np.float32 if dtype == "f32" else np.float64
+    if N > 256:
+        rng = np.random.RandomState(3)
+        x = rng.standard_normal((N + 2,) * 3).astype(npdt)
+        x0 = rng.standard_normal((N + 2,) * 3).astype(npdt)
+        t0 = time.perf_counter()
+        O.lin_solve(0, x, x0, npdt(0.3), npdt(2.8), K)
+        el = time.perf_counter() - t0
+        sweeps = N ** 3 * K / el / 1e6
+        return {"value": sweeps * 3 * K / words_per_cell_step(K) / K, "unit": "Mcells/s", "cores": 1, "kind": "port",
+                "sample": f"one lin_solve of {K} Jacobi iterations at {N}^3 {dtype} ({el:.1f} s, {sweeps:.0f} Mcell-sweeps/s), "
+                          f"scaled to a full step by (56+18K)/(3K) words; serial C++ oracle (g++ -O2 -ffp-contract=off)",
+                "host_cores_visible": os.cpu_count()}
     f = analytic_planes(N, 0, N + 2, dt, npdt)
     fields = {"u": f["u"], "v": f["v"], "w": f["w"], "dens": f["dens"]}
     for b, n in ((1, "u"), (2, "v"), (3, "w"), (0, "dens")):

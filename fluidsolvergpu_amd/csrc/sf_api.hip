@@ -218,11 +218,11 @@ public:
         // but with one 512-thread workgroup per CU it is latency-bound — 305 vs 267 us/sweep at 512^3)
         fuse2_ = env_int("SF_FUSE2", 1);
         kc2_ = env_int("SF_KC2", 32);
-        f2_shape_ = env_int("SF_F2", 22);
         advect_lds_ = env_int("SF_ADVECT_LDS", 0) != 0;
         zero_skip_ = env_int("SF_ZERO_SKIP", 1) != 0;
         fuse_maxvec_ = env_int("SF_FUSE_MAXVEC", 128);
         tx_override_ = env_int("SF_TX", 0);
+        split_enabled_ = env_int("SF_SPLIT", 1) != 0;
         SF_HIP(hipDeviceSynchronize());
     }
 
@@ -802,7 +802,7 @@ private:
             SF_HIP(hipGetLastError());
             return;
         }
-        const bool two_streams = can_split && nzl_ > 2 * depth && env_int("SF_SPLIT", 1) != 0 && !interior_reads_ghosts;
+        const bool two_streams = can_split && nzl_ > 2 * depth && split_enabled_ && !interior_reads_ghosts;
         if (!two_streams) join();
         for (Slab& sl : slabs_) {
             if (!two_streams) {
@@ -1231,13 +1231,13 @@ private:
     int L_ = 1, nranks_ = 1, rank_ = 0, P_ = 1, G_ = 1;
     int fuse_maxvec_ = 128;
     int bound_[4] = {-1, -1, -1, -1};  // resident source slots (sf_bind_sources)
-    bool pending_join_ = false;
+    bool pending_join_ = false, split_enabled_ = true;
     int split_ = INT_MAX, gap_ = 0;  // plane-range split of the launch being issued (for_planes)
     T dt_{}, diff_{}, visc_{};
     int num_cu_ = 256;
     int nzl_ = 0, lead_ = 0, px_ = 0, nplanes_ = 0, kchunk_ = 0, jacobi_mode_ = 2, tx_override_ = 0, nt_mode_ = 2, rb_shape_ = 0;
     bool ishell_skip_ = true, advect_lds_ = false, zero_skip_ = true, x_is_zero_ = false;
-    int fuse2_ = 1, kc2_ = 32, f2_shape_ = 22;
+    int fuse2_ = 1, kc2_ = 32;
     long plane_ = 0, field_elems_ = 0;
     std::vector<Slab> slabs_;
     ncclComm_t comm_ = nullptr;
