@@ -439,6 +439,31 @@ def test_bound_sources(P):
         assert_same(got[n], f[n], f"bound sources P={P}: {n}")
 
 
+def test_graph_replay_matches(monkeypatch):
+    """SF_GRAPH=1: steps captured into hipGraphs and replayed (several buffer arrangements, odd K) equal the oracle."""
+    monkeypatch.setenv("SF_GRAPH", "1")
+    N, dtype, K = 20, np.float32, 5
+    f = small_velocity(rand_fields(N, dtype, 80), N, dtype)
+    src = {n: f[n].copy() for n in ("u0", "v0", "w0", "dens0")}
+    with make(N, dtype, K=K) as fs:
+        for n in ("u", "v", "w", "dens"):
+            fs.upload(n, f[n])
+        for slot, n in (("user0", "u0"), ("user1", "v0"), ("user2", "w0"), ("user3", "dens0")):
+            fs.upload(slot, src[n])
+        fs.bind_sources("user0", "user1", "user2", "user3")
+        for _ in range(6):
+            fs.vel_step()
+            fs.dens_step()
+        fs.sync()
+        got = {n: fs.download(n) for n in ("u", "v", "w", "dens")}
+    for _ in range(6):
+        for n in src:
+            f[n][...] = src[n]
+        O.step(N, f, dtype(DT), dtype(DIFF), dtype(VISC), K)
+    for n in got:
+        assert_same(got[n], f[n], f"graph replay: {n}")
+
+
 def test_invalid_arguments_are_rejected():
     Sx = S()
     with pytest.raises(Sx.SfError):
