@@ -1158,7 +1158,7 @@ private:
     void launch_jacobi2(Slab& sl, const sfk::JacobiArgs<T, NF>& A, int kb, int ke, bool first, bool last) {
         const bool nt = nt_mode_ == 1 ||
                         (nt_mode_ == 2 && (size_t)field_elems_ * sizeof(T) * 3 * NF > ((size_t)384 << 20));
-        if (can_march2()) {
+        if (can_march2() && !x_is_zero_) {  // the implicit-zero first pair only exists in the register kernel
             if (nt)
                 launch_march2<NF, true>(sl, A, kb, ke, first, last);
             else
