@@ -223,6 +223,7 @@ public:
         fuse_maxvec_ = env_int("SF_FUSE_MAXVEC", 128);
         tx_override_ = env_int("SF_TX", 0);
         split_enabled_ = env_int("SF_SPLIT", 1) != 0;
+        strip_mode_ = env_int("SF_STRIP", 0);  // 0 heuristic, 1 dense, 2 wave-aligned row strips in the fused kernel
         graphs_ = env_int("SF_GRAPH", 0) != 0 && P_ == 1;
         SF_HIP(hipDeviceSynchronize());
     }
@@ -1101,7 +1102,16 @@ private:
     void launch_fused2(Slab& sl, const sfk::JacobiArgs<T, NF>& A, int kb, int ke, bool first, bool last) {
         const int nvec = N_ / W;
         sfk::TileMap m{};
-        m.rows = std::max(1, 256 / nvec);  // row strips per 256-thread workgroup
+        // row strips per 256-thread workgroup: packed densely (strip = nvec lanes; rows then start anywhere inside a
+        // wave and both ends of most waves are seams -> LDS hand-over of x) or aligned to wave boundaries (strip
+        // = multiple of 64; idle lanes, but one seam per wave at most). Aligned wins unless it idles >10 % more lanes.
+        const int aligned = ceil_div(nvec, 64) * 64;
+        const double eff_dense = (double)((256 / nvec) * nvec), eff_aligned = (double)((256 / aligned) * nvec);
+        m.strip = (nvec % 64 == 0 || 64 % nvec == 0 || eff_aligned >= 0.9 * eff_dense) ? std::max(aligned, nvec) : nvec;
+        if (strip_mode_ == 1) m.strip = nvec;
+        if (strip_mode_ == 2) m.strip = std::max(aligned, nvec);
+        if (64 % nvec == 0) m.strip = nvec;  // narrow rows: several whole rows per wave, never a seam
+        m.rows = std::max(1, 256 / m.strip);
         m.gx = 1;
         m.gy = ceil_div(N_, m.rows * RJ);
         m.nxcd = 8;
@@ -1112,7 +1122,7 @@ private:
         m.gap = gap_;
         const long per_plane = m.band > 0 ? (long)m.nxcd * m.band : (long)m.gy;
         const long nblocks = per_plane * ceil_div(ke - kb, RK) * NF;
-        const bool xlds = nvec % 64 != 0 && 64 % nvec != 0;
+        const bool xlds = m.strip % 64 != 0 && 64 % m.strip != 0;
         if (NF == 1 && x_is_zero_) {
             if (xlds)
                 hipLaunchKernelGGL((sfk::jacobi2_kernel<T, 1, NT, RJ, RK, true, true>), dim3((unsigned)nblocks), dim3(256),
@@ -1306,7 +1316,7 @@ private:
 
     int N_, K_, device_;
     int L_ = 1, nranks_ = 1, rank_ = 0, P_ = 1, G_ = 1;
-    int fuse_maxvec_ = 128;
+    int fuse_maxvec_ = 128, strip_mode_ = 0;
     int bound_[4] = {-1, -1, -1, -1};  // resident source slots (sf_bind_sources)
     bool pending_join_ = false, split_enabled_ = true, graphs_ = false;
     std::vector<GraphEntry> graph_cache_;

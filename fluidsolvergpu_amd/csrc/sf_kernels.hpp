@@ -323,7 +323,9 @@ struct TileMap {
     // of the kernel's plane block; no split: split = INT_MAX, gap = 0.
     int split;
     int gap;
-    int rows;  // jacobi2_kernel: row strips per workgroup (256 threads hold `rows` strips of N/W vectors each)
+    int rows;   // jacobi2_kernel: row strips per workgroup
+    int strip;  // jacobi2_kernel: lanes reserved per strip (>= N/W; N/W itself packs strips densely, a multiple of
+                // 64 keeps every strip aligned to wave boundaries at the price of idle lanes)
 };
 
 __device__ __forceinline__ int plane_of(const TileMap& m, int kb, int t) {
@@ -571,12 +573,13 @@ __global__ void __launch_bounds__(256, SF_J2_WAVES) jacobi2_kernel(Geom g, Jacob
     // 256 threads in a line hold m.rows row strips of nvec vectors each: rows need not start at a wave
     // boundary, so a wave seam can fall anywhere inside a row (handled through LDS below)
     const int tid = (int)threadIdx.x;
-    const int strip = tid / nvec;
-    int vec = tid - strip * nvec;
+    const int strip = tid / m.strip;
+    int vec = tid - strip * m.strip;
     int j0 = 1 + (jt * m.rows + strip) * RJ;
-    const bool active = tile_ok && strip < m.rows && j0 <= N;
+    const bool active = tile_ok && strip < m.rows && vec < nvec && j0 <= N;
     // out-of-range threads keep running on clamped (valid) addresses so that every wave reaches the
     // barrier and every DPP source lane is alive; they store nothing
+    vec = vec < nvec ? vec : nvec - 1;
     j0 = (tile_ok && strip < m.rows && j0 <= N) ? j0 : N;
     const int i0 = 1 + W * vec;
     const T a = A.a, inv = A.inv;
@@ -639,7 +642,7 @@ __global__ void __launch_bounds__(256, SF_J2_WAVES) jacobi2_kernel(Geom g, Jacob
     const bool first_vec = (vec == 0), last_vec = (vec == nvec - 1);
     const bool has_left = lane != 0, has_right = lane != 63;  // neighbour vector lives in the same wave
 
-    const bool multi_wave = (64 % nvec) != 0;  // some row crosses a wave boundary
+    const bool multi_wave = (64 % m.strip) != 0;  // some row crosses a wave boundary
     // ---- x end cells cross waves through LDS (cheaper than two masked per-lane loads per position) ---------
     if (XLDS && !XZ && multi_wave) {
 #pragma unroll
