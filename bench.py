@@ -30,7 +30,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured float4 copy)
-WEAK_GRID = {1: 256, 2: 324, 4: 408, 8: 512}  # N_g^3 / gpus ~= 256^3, N_g divisible by gpus and by 4
+WEAK_GRID = {1: 256, 2: 320, 4: 408, 8: 512}  # N_g^3 / gpus ~= 256^3, N_g divisible by gpus and by 4
 
 
 def parse():

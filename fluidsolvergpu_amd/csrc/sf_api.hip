@@ -133,7 +133,8 @@ public:
         SF_REQUIRE(rank_ >= 0 && rank_ < nranks_, "rank out of range");
         P_ = nranks_ * L_;
         SF_REQUIRE(N_ % P_ == 0, "N must be divisible by nranks*nslabs_local");
-        SF_REQUIRE(nranks_ == 1 || p.nccl_id != nullptr, "nccl_id required when nranks > 1");
+        loopback_ = (p.flags & SF_FLAG_LOOPBACK_HALO) != 0;
+        SF_REQUIRE(nranks_ == 1 || loopback_ || p.nccl_id != nullptr, "nccl_id required when nranks > 1");
         set_coefficients(p.dt, p.diff, p.visc);
 
         int ndev = 0;
@@ -180,7 +181,13 @@ public:
             sl.geom.wall_hi = (sl.gid == P_ - 1);
             SF_HIP(hipStreamCreateWithFlags(&sl.cs, hipStreamNonBlocking));
             SF_HIP(hipStreamCreateWithFlags(&sl.bs, hipStreamNonBlocking));
-            SF_HIP(hipEventCreateWithFlags(&sl.cs_mark, hipEventDisableTiming));
+            // Events that only order kernels of THIS device against each other skip the system-scope fence of the
+            // default event (a cache write-back + invalidate per record: ~12 us between consecutive sweeps of a
+            // decomposed grid). halo_done keeps it when the ghost planes are written by another GPU through RCCL.
+            const unsigned ev_local =
+                hipEventDisableTiming | (env_int("SF_EVENT_FENCE", 0) ? 0u : (unsigned)hipEventDisableSystemFence);
+            const unsigned ev_halo = (nranks_ > 1 && !loopback_) ? (unsigned)hipEventDisableTiming : ev_local;
+            SF_HIP(hipEventCreateWithFlags(&sl.cs_mark, ev_local));
             sl.cur = sl.cs;
             {
                 // SF_HALO_PRIO=1 gives the halo stream the highest priority so its traffic does not queue behind the
@@ -193,8 +200,8 @@ public:
                 else
                     SF_HIP(hipStreamCreateWithFlags(&sl.hs, hipStreamNonBlocking));
             }
-            SF_HIP(hipEventCreateWithFlags(&sl.boundary_done, hipEventDisableTiming));
-            SF_HIP(hipEventCreateWithFlags(&sl.halo_done, hipEventDisableTiming));
+            SF_HIP(hipEventCreateWithFlags(&sl.boundary_done, ev_local));
+            SF_HIP(hipEventCreateWithFlags(&sl.halo_done, ev_halo));
             for (int f = 0; f < SF_USER0; ++f) sl.field[f] = alloc_field();
             for (int f = 0; f < NSCRATCH; ++f) sl.scratch[f] = alloc_field();
             SF_HIP(hipMalloc(&sl.d_flag, sizeof(int)));
@@ -203,7 +210,7 @@ public:
         }
         SF_HIP(hipEventCreate(&t0_));
         SF_HIP(hipEventCreate(&t1_));
-        if (nranks_ > 1) {
+        if (nranks_ > 1 && !loopback_) {
             ncclUniqueId id;
             static_assert(sizeof(ncclUniqueId) <= SF_NCCL_ID_BYTES, "ncclUniqueId larger than ABI slot");
             std::memcpy(&id, p.nccl_id, sizeof id);
@@ -223,6 +230,8 @@ public:
         fuse_maxvec_ = env_int("SF_FUSE_MAXVEC", 128);
         tx_override_ = env_int("SF_TX", 0);
         split_enabled_ = env_int("SF_SPLIT", 1) != 0;
+        ovl_mode_ = env_int("SF_OVL", 1);
+        trap_m_ = env_int("SF_TRAP", 5);  // pairs per trapezoid block of a decomposed lin_solve (<= 1: off)
         strip_mode_ = env_int("SF_STRIP", 0);  // 0 heuristic, 1 dense, 2 wave-aligned row strips in the fused kernel
         graphs_ = env_int("SF_GRAPH", 0) != 0 && P_ == 1;
         SF_HIP(hipDeviceSynchronize());
@@ -880,8 +889,14 @@ private:
             SF_HIP(hipGetLastError());
             return;
         }
+        // trap_extra_ > 0 (lin_solve only): the boundary launch takes that many more planes per side than the last
+        // one did, so this interior launch reads nothing a boundary launch wrote since the last resync and the
+        // compute stream needs no cross-stream wait (see op_lin_solve)
+        const int extra = (can_split && nzl_ > 2 * (depth + trap_extra_) && split_enabled_ && !interior_reads_ghosts)
+                              ? trap_extra_ : 0;
         const bool two_streams = can_split && nzl_ > 2 * depth && split_enabled_ && !interior_reads_ghosts;
         if (!two_streams) join();
+        depth += extra;
         for (Slab& sl : slabs_) {
             if (!two_streams) {
                 sl.cur = sl.cs;
@@ -896,8 +911,9 @@ private:
                 }
                 continue;
             }
-            // I of this operator reads what the previous B wrote; B reads everything issued on cs so far
-            SF_HIP(hipStreamWaitEvent(sl.cs, sl.boundary_done, 0));
+            // I of this operator reads what the previous B wrote (unless B has grown, see above); B reads everything
+            // issued on cs so far
+            if (extra == 0) SF_HIP(hipStreamWaitEvent(sl.cs, sl.boundary_done, 0));
             SF_HIP(hipEventRecord(sl.cs_mark, sl.cs));
             SF_HIP(hipStreamWaitEvent(sl.bs, sl.cs_mark, 0));
             // ONE launch over the first and the last `depth` interior planes (split plane range)
@@ -912,6 +928,12 @@ private:
             launch(sl, kb + depth, ke - depth);
         }
         SF_HIP(hipGetLastError());
+    }
+
+    // Kernel launch on sl.cur.
+    template <class F, class... Args>
+    void launch_k(Slab& sl, F kernel, unsigned nblocks, unsigned nthreads, Args... args) {
+        hipLaunchKernelGGL(kernel, dim3(nblocks), dim3(nthreads), 0, sl.cur, args...);
     }
 
     // Halo exchange of NF fields: first / last interior plane -> neighbour's ghost plane.
@@ -953,7 +975,26 @@ private:
             }
             // neighbours in other processes: grouped send/recv over RCCL (xGMI point-to-point)
             const bool lo_remote = has_lo && !lo_local, hi_remote = has_hi && !hi_local;
-            if (lo_remote || hi_remote) {
+            if ((lo_remote || hi_remote) && loopback_) {
+                // SF_FLAG_LOOPBACK_HALO: same bytes, same stream, same dependencies, but from this slab's own planes
+                sfk::HaloCopyArgs H;
+                H.nseg = 0;
+                H.n16 = (long)(bytes / 16);
+                for (int f = 0; f < NF; ++f) {
+                    T* mine = sl.field[fields[f]];
+                    if (lo_remote) {
+                        H.src[H.nseg] = reinterpret_cast<const float4*>(mine + send_lo);
+                        H.dst[H.nseg++] = reinterpret_cast<float4*>(mine + recv_lo);
+                    }
+                    if (hi_remote) {
+                        H.src[H.nseg] = reinterpret_cast<const float4*>(mine + send_hi);
+                        H.dst[H.nseg++] = reinterpret_cast<float4*>(mine + recv_hi);
+                    }
+                }
+                const unsigned gx = (unsigned)std::max(1L, std::min((H.n16 + 255) / 256, 512L));
+                hipLaunchKernelGGL(sfk::halo_copy_kernel, dim3(gx, H.nseg), dim3(256), 0, sl.hs, H);
+                SF_HIP(hipGetLastError());
+            } else if (lo_remote || hi_remote) {
                 const ncclDataType_t dt = sizeof(T) == 4 ? ncclFloat : ncclDouble;
                 SF_NCCL(ncclGroupStart());
                 for (int f = 0; f < NF; ++f) {
@@ -1120,22 +1161,33 @@ private:
         m.ishell_write = (!ishell_skip_ || last) ? 1 : 0;
         m.split = split_;
         m.gap = gap_;
+        // rows that neither fill whole waves nor divide one: the seam-free overlapped mapping (SF_OVL: 0 never,
+        // 1 for such rows (default), 2 for every width)
+        const bool ovl = ovl_mode_ == 2 || (ovl_mode_ == 1 && nvec % 64 != 0 && 64 % nvec != 0);
+        if (ovl) {
+            const int items = ceil_div(N_, RJ) * nvec;
+            m.gy = ceil_div(ceil_div(items, sfk::SF_OVL_OUT), 4);
+            m.band = (jacobi_mode_ >= 2 && m.gy >= 16) ? ceil_div(m.gy, 8) : 0;
+        }
         const long per_plane = m.band > 0 ? (long)m.nxcd * m.band : (long)m.gy;
         const long nblocks = per_plane * ceil_div(ke - kb, RK) * NF;
         const bool xlds = m.strip % 64 != 0 && 64 % m.strip != 0;
-        if (NF == 1 && x_is_zero_) {
-            if (xlds)
-                hipLaunchKernelGGL((sfk::jacobi2_kernel<T, 1, NT, RJ, RK, true, true>), dim3((unsigned)nblocks), dim3(256),
-                                   0, sl.cur, sl.geom, first_field(A), kb, ke, m);
+        const unsigned nb = (unsigned)nblocks;
+        if (ovl) {
+            if (NF == 1 && x_is_zero_)
+                launch_k(sl, sfk::jacobi2_kernel<T, 1, NT, RJ, RK, false, true, true>, nb, 256u, sl.geom, first_field(A), kb,
+                         ke, m);
             else
-                hipLaunchKernelGGL((sfk::jacobi2_kernel<T, 1, NT, RJ, RK, false, true>), dim3((unsigned)nblocks), dim3(256),
-                                   0, sl.cur, sl.geom, first_field(A), kb, ke, m);
+                launch_k(sl, sfk::jacobi2_kernel<T, NF, NT, RJ, RK, false, false, true>, nb, 256u, sl.geom, A, kb, ke, m);
+        } else if (NF == 1 && x_is_zero_) {
+            if (xlds)
+                launch_k(sl, sfk::jacobi2_kernel<T, 1, NT, RJ, RK, true, true>, nb, 256u, sl.geom, first_field(A), kb, ke, m);
+            else
+                launch_k(sl, sfk::jacobi2_kernel<T, 1, NT, RJ, RK, false, true>, nb, 256u, sl.geom, first_field(A), kb, ke, m);
         } else if (xlds) {
-            hipLaunchKernelGGL((sfk::jacobi2_kernel<T, NF, NT, RJ, RK, true>), dim3((unsigned)nblocks), dim3(256), 0,
-                               sl.cur, sl.geom, A, kb, ke, m);
+            launch_k(sl, sfk::jacobi2_kernel<T, NF, NT, RJ, RK, true>, nb, 256u, sl.geom, A, kb, ke, m);
         } else {
-            hipLaunchKernelGGL((sfk::jacobi2_kernel<T, NF, NT, RJ, RK, false>), dim3((unsigned)nblocks), dim3(256), 0,
-                               sl.cur, sl.geom, A, kb, ke, m);
+            launch_k(sl, sfk::jacobi2_kernel<T, NF, NT, RJ, RK, false>, nb, 256u, sl.geom, A, kb, ke, m);
         }
     }
 
@@ -1198,11 +1250,22 @@ private:
                 ensure(sl, x[f]);
                 ensure(sl, x0[f]);
             }
+        // Decomposed grid, fused pairs: a cross-stream wait in front of every interior launch costs ~10 us of idle
+        // GPU per pair (measured: tools/evgap.hip, profiles of tools/rank_share.py). So the boundary launch grows by
+        // two planes per side and pair ("trapezoid") for trap_m_ pairs: interior launch j then covers planes
+        // [G+2+2j, ...) and reads only what interior launch j-1 wrote (planes [G+2j, ...)), back to back on the
+        // compute stream, while boundary launch j (planes [G, G+2+2j), on its own stream, after interior j-1 and halo
+        // j-1) feeds the halo exchange. Every trap_m_ pairs the interior snaps back and waits for the boundary once.
+        // Same arithmetic on every plane whichever launch computes it: results do not change.
+        int tj = 0;
         int it = 0;
         while (it < K) {
             const bool pair = can_fuse2() && it + 2 <= K;
             const int step = pair ? 2 : 1;
             x_is_zero_ = x_zero && it == 0 && pair;  // the first fused pair then loads no x at all
+            if (!pair || trap_m_ <= 1 || tj >= trap_m_ || nzl_ <= 2 * (G_ + 2 * tj) + 2) tj = 0;
+            trap_extra_ = (pair && P_ > 1 && G_ == 2) ? 2 * tj : 0;
+            ++tj;
             for_planes([&](Slab& sl, int kb, int ke) {
                 sfk::JacobiArgs<T, NF> A;
                 for (int f = 0; f < NF; ++f) {
@@ -1224,6 +1287,7 @@ private:
             exchange<NF>(x);
             it += step;
         }
+        trap_extra_ = 0;
         x_is_zero_ = false;
     }
 
@@ -1316,7 +1380,8 @@ private:
 
     int N_, K_, device_;
     int L_ = 1, nranks_ = 1, rank_ = 0, P_ = 1, G_ = 1;
-    int fuse_maxvec_ = 128, strip_mode_ = 0;
+    int fuse_maxvec_ = 128, strip_mode_ = 0, ovl_mode_ = 1;
+    int trap_m_ = 4, trap_extra_ = 0;
     int bound_[4] = {-1, -1, -1, -1};  // resident source slots (sf_bind_sources)
     bool pending_join_ = false, split_enabled_ = true, graphs_ = false;
     std::vector<GraphEntry> graph_cache_;
@@ -1329,6 +1394,7 @@ private:
     long plane_ = 0, field_elems_ = 0;
     std::vector<Slab> slabs_;
     ncclComm_t comm_ = nullptr;
+    bool loopback_ = false;
     hipEvent_t t0_ = nullptr, t1_ = nullptr;
     T* tr_pos_ = nullptr;
     T* tr_dens_ = nullptr;

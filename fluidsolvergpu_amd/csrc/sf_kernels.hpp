@@ -455,6 +455,27 @@ __global__ void __launch_bounds__(256) jacobi_rb_kernel(Geom g, JacobiArgs<T, NF
     const bool has_left = ((int)threadIdx.x & 63) != 0;
     const bool has_right = (((int)threadIdx.x + 1) & 63) != 0 && (int)threadIdx.x + 1 < (int)blockDim.x;
     const bool first_vec = (i0 == 1), last_vec = (i0 + W - 1 >= N);
+    // end cells no lane of this wave holds: requested here, together with the vector loads (a load at the point of
+    // use would be a dependent memory round trip per output position)
+    const bool left_mem = first_vec ? m.ishell_mem != 0 : !has_left;
+    const bool right_mem = last_vec ? m.ishell_mem != 0 : !has_right;
+    T XL[RK][RJ], XR[RK][RJ];
+#pragma unroll
+    for (int rk = 0; rk < RK; ++rk)
+#pragma unroll
+        for (int rj = 0; rj < RJ; ++rj) XL[rk][rj] = XR[rk][rj] = T(0);
+    if (left_mem) {
+#pragma unroll
+        for (int rk = 0; rk < RK; ++rk)
+#pragma unroll
+            for (int rj = 0; rj < RJ; ++rj) XL[rk][rj] = x[planeq[rk + 1] + rowq[rj + 1] - 1];
+    }
+    if (right_mem) {
+#pragma unroll
+        for (int rk = 0; rk < RK; ++rk)
+#pragma unroll
+            for (int rj = 0; rj < RJ; ++rj) XR[rk][rj] = x[planeq[rk + 1] + rowq[rj + 1] + W];
+    }
 
 #pragma unroll
     for (int rk = 0; rk < RK; ++rk) {
@@ -474,12 +495,12 @@ __global__ void __launch_bounds__(256) jacobi_rb_kernel(Geom g, JacobiArgs<T, NF
                 if (e == nv - 1) last = c[e];
             T xm, xp;
             if (first_vec)
-                xm = m.ishell_mem ? x[q - 1] : sx * c[0];
+                xm = m.ishell_mem ? XL[rk][rj] : sx * c[0];
             else
-                xm = has_left ? up : x[q - 1];
+                xm = has_left ? up : XL[rk][rj];
             if (last_vec) {
                 if (m.ishell_mem) {
-                    xp = x[q + W];
+                    xp = XR[rk][rj];
                 } else {
                     xp = sx * last;
                     if (nv < W) {  // the shell cell N+1 lies inside this vector: patch it
@@ -489,7 +510,7 @@ __global__ void __launch_bounds__(256) jacobi_rb_kernel(Geom g, JacobiArgs<T, NF
                     }
                 }
             } else {
-                xp = has_right ? dn : x[q + W];
+                xp = has_right ? dn : XR[rk][rj];
             }
             const V km = X[rk][rj], kp = X[rk + 2][rj];
             const V jm = (rj == 0) ? Jlo[rk] : X[rk + 1][rj > 0 ? rj - 1 : 0];
@@ -535,9 +556,20 @@ __global__ void __launch_bounds__(256) jacobi_rb_kernel(Geom g, JacobiArgs<T, NF
 // XZ: the incoming iterate is identically zero (project's p = 0): no x is loaded at all — the same operations
 // are applied to literal zeros, so the bits equal a sweep over a zero-filled field — and the caller can skip the
 // memset of p.
-template <class T, int NF, bool NT, int RJ, int RK, bool XLDS, bool XZ = false>
+// OVL: seam-free mapping for rows of any width. The (row pair, vector) items of a plane pair are numbered in memory
+// order and every wave takes 60 consecutive ones in lanes 2..61; lanes 0, 1 and 62, 63 hold the two items before /
+// after them and only feed the shuffles (x of the outer one, y of the inner one), so nothing crosses waves: no
+// LDS, no barrier, and 94 % of the lanes produce output whatever N/W is (a row end inside a wave is handled by the
+// same in-register i-shell logic as everywhere else).
+#ifndef SF_OVL_OUT_N
+#define SF_OVL_OUT_N 60
+#endif
+constexpr int SF_OVL_OUT = SF_OVL_OUT_N;
+constexpr int SF_OVL_LO = (64 - SF_OVL_OUT_N) / 2;  // first output lane
+template <class T, int NF, bool NT, int RJ, int RK, bool XLDS, bool XZ = false, bool OVL = false>
 __global__ void __launch_bounds__(256, SF_J2_WAVES) jacobi2_kernel(Geom g, JacobiArgs<T, NF> A, int kb, int ke,
                                                        TileMap m) {
+    static_assert(!(OVL && XLDS), "the overlapped mapping has no seams");
     constexpr int W = VecT<T>::W;
     typedef typename VecT<T>::type V;
     constexpr int NPOS = RJ * RK;
@@ -573,14 +605,27 @@ __global__ void __launch_bounds__(256, SF_J2_WAVES) jacobi2_kernel(Geom g, Jacob
     // 256 threads in a line hold m.rows row strips of nvec vectors each: rows need not start at a wave
     // boundary, so a wave seam can fall anywhere inside a row (handled through LDS below)
     const int tid = (int)threadIdx.x;
-    const int strip = tid / m.strip;
-    int vec = tid - strip * m.strip;
-    int j0 = 1 + (jt * m.rows + strip) * RJ;
-    const bool active = tile_ok && strip < m.rows && vec < nvec && j0 <= N;
-    // out-of-range threads keep running on clamped (valid) addresses so that every wave reaches the
-    // barrier and every DPP source lane is alive; they store nothing
-    vec = vec < nvec ? vec : nvec - 1;
-    j0 = (tile_ok && strip < m.rows && j0 <= N) ? j0 : N;
+    int vec, j0;
+    bool active;
+    if (OVL) {
+        if (!tile_ok) return;  // no barrier in this mapping
+        const int total = ((N + RJ - 1) / RJ) * nvec;
+        int t = (jt * 4 + (tid >> 6)) * SF_OVL_OUT + (tid & 63) - SF_OVL_LO;
+        active = t >= 0 && t < total && (tid & 63) >= SF_OVL_LO && (tid & 63) < SF_OVL_LO + SF_OVL_OUT;
+        t = t < 0 ? 0 : (t >= total ? total - 1 : t);  // feeder / padding lanes run on valid addresses
+        const int rg = t / nvec;
+        vec = t - rg * nvec;
+        j0 = 1 + rg * RJ;
+    } else {
+        const int strip = tid / m.strip;
+        vec = tid - strip * m.strip;
+        j0 = 1 + (jt * m.rows + strip) * RJ;
+        active = tile_ok && strip < m.rows && vec < nvec && j0 <= N;
+        // out-of-range threads keep running on clamped (valid) addresses so that every wave reaches the
+        // barrier and every DPP source lane is alive; they store nothing
+        vec = vec < nvec ? vec : nvec - 1;
+        j0 = (tile_ok && strip < m.rows && j0 <= N) ? j0 : N;
+    }
     const int i0 = 1 + W * vec;
     const T a = A.a, inv = A.inv;
     const T* __restrict__ x = A.x[0];
@@ -640,9 +685,35 @@ __global__ void __launch_bounds__(256, SF_J2_WAVES) jacobi2_kernel(Geom g, Jacob
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const bool first_vec = (vec == 0), last_vec = (vec == nvec - 1);
-    const bool has_left = lane != 0, has_right = lane != 63;  // neighbour vector lives in the same wave
+    // neighbour vector lives in the same wave (always, for the lanes that matter, in the overlapped mapping)
+    const bool has_left = OVL || lane != 0, has_right = OVL || lane != 63;
 
-    const bool multi_wave = (64 % m.strip) != 0;  // some row crosses a wave boundary
+    const bool multi_wave = !OVL && (64 % m.strip) != 0;  // some row crosses a wave boundary
+    // End cells of x that no lane of this wave holds (the i-shell cells of caller data in a first sweep; the cell
+    // across a wave seam when seams are not handed over through LDS): all of them are requested HERE, back to back
+    // with the vector loads above. Loading each one where it is used costs a dependent memory round trip per
+    // first-sweep position (12 in a row: the compiler cannot hoist a load out of its divergent branch).
+    const bool left_mem = !XZ && (first_vec ? m.ishell_mem != 0 : (!has_left && !XLDS));
+    const bool right_mem = !XZ && (last_vec ? m.ishell_mem != 0 : (!has_right && !XLDS));
+    T XL[NYPOS], XR[NYPOS];
+#pragma unroll
+    for (int pos = 0; pos < NYPOS; ++pos) XL[pos] = XR[pos] = T(0);
+    if (left_mem) {
+#pragma unroll
+        for (int c = -1; c <= RK; ++c)
+#pragma unroll
+            for (int r = -1; r <= RJ; ++r)
+                if (SF_DIST(c, RK) + SF_DIST(r, RJ) <= 1)
+                    XL[(c + 1) * (RJ + 2) + (r + 1)] = x[planeq[c + 2] + rowq[r + 2] - 1];
+    }
+    if (right_mem) {
+#pragma unroll
+        for (int c = -1; c <= RK; ++c)
+#pragma unroll
+            for (int r = -1; r <= RJ; ++r)
+                if (SF_DIST(c, RK) + SF_DIST(r, RJ) <= 1)
+                    XR[(c + 1) * (RJ + 2) + (r + 1)] = x[planeq[c + 2] + rowq[r + 2] + W];
+    }
     // ---- x end cells cross waves through LDS (cheaper than two masked per-lane loads per position) ---------
     if (XLDS && !XZ && multi_wave) {
 #pragma unroll
@@ -666,7 +737,6 @@ __global__ void __launch_bounds__(256, SF_J2_WAVES) jacobi2_kernel(Geom g, Jacob
             const V cc = X[c + 2][r + 2];
             const T up = lane_up(cc[W - 1]);
             const T dn = lane_dn(cc[0]);
-            const long q = planeq[c + 2] + rowq[r + 2];
             const int pos = (c + 1) * (RJ + 2) + (r + 1);
             T xm, xp;
             if (XZ) {
@@ -674,13 +744,13 @@ __global__ void __launch_bounds__(256, SF_J2_WAVES) jacobi2_kernel(Geom g, Jacob
                 xp = T(0);
             } else {
                 if (first_vec)
-                    xm = m.ishell_mem ? x[q - 1] : sx * cc[0];
+                    xm = m.ishell_mem ? XL[pos] : sx * cc[0];
                 else
-                    xm = has_left ? up : (XLDS ? shx_last[wave > 0 ? wave - 1 : 0][pos] : x[q - 1]);
+                    xm = has_left ? up : (XLDS ? shx_last[wave > 0 ? wave - 1 : 0][pos] : XL[pos]);
                 if (last_vec)
-                    xp = m.ishell_mem ? x[q + W] : sx * cc[W - 1];
+                    xp = m.ishell_mem ? XR[pos] : sx * cc[W - 1];
                 else
-                    xp = has_right ? dn : (XLDS ? shx_first[wave < 3 ? wave + 1 : 3][pos] : x[q + W]);
+                    xp = has_right ? dn : (XLDS ? shx_first[wave < 3 ? wave + 1 : 3][pos] : XR[pos]);
             }
             const V km = X[c + 1][r + 2], kp = X[c + 3][r + 2];
             const V jm = X[c + 2][r + 1], jp = X[c + 2][r + 3];

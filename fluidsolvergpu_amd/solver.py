@@ -109,14 +109,14 @@ class FluidSolver:
     (C order, i fastest), i.e. exactly the dense IX(i,j,k) layout of docs/SPEC.md."""
 
     def __init__(self, N, dtype="f32", iters=20, dt=0.1, diff=1e-4, visc=1e-4, device=0, nslabs_local=1,
-                 rank=0, nranks=1, nccl_id=None):
+                 rank=0, nranks=1, nccl_id=None, flags=0):
         self.N = int(N)
         self.np_dtype = np.float32 if dtype in ("f32", np.float32, SF_F32) else np.float64
         self._id_buf = C.create_string_buffer(nccl_id, NCCL_ID_BYTES) if nccl_id is not None else None
         p = SfParams(N=self.N, dtype=SF_F32 if self.np_dtype == np.float32 else SF_F64, iters=int(iters),
                      dt=float(dt), diff=float(diff), visc=float(visc), device=int(device),
                      nslabs_local=int(nslabs_local), rank=int(rank), nranks=int(nranks),
-                     nccl_id=C.cast(self._id_buf, C.c_void_p) if self._id_buf is not None else None, flags=0)
+                     nccl_id=C.cast(self._id_buf, C.c_void_p) if self._id_buf is not None else None, flags=int(flags))
         self._h = _ctx()
         rc = lib.sf_create(C.byref(self._h), C.byref(p))
         if rc != SF_OK:

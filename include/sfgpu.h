@@ -60,8 +60,14 @@ typedef struct sf_params {
     int nslabs_local; /* logical k-slabs held by this context (>= 1); total = nranks * this     */
     int rank, nranks; /* this process / number of processes (one per GPU). nranks == 1: no RCCL */
     const void* nccl_id; /* SF_NCCL_ID_BYTES from sf_nccl_unique_id() of rank 0 when nranks > 1 */
-    int flags;        /* reserved, 0                                                            */
+    int flags;        /* 0, or SF_FLAG_* bits                                                   */
 } sf_params;
+
+/* Measurement aid: the context takes the geometry, streams and launch schedule of rank `rank` of `nranks`, but the
+ * halo messages to ranks in other processes become device-local copies of its own planes of the same size and no
+ * communicator is created (nccl_id may be NULL). Timing of one rank's share on a single GPU; the field values
+ * next to the slab boundaries are then meaningless. */
+#define SF_FLAG_LOOPBACK_HALO 1
 
 /* Library / build identification ("sfgpu <ver> gfx950 hip"). */
 const char* sf_version(void);
