@@ -202,16 +202,21 @@ template <class T, int NF>
 __global__ void __launch_bounds__(256) add_source_kernel(AddSourceArgs<T, NF> A) {
     constexpr int W = VecT<T>::W;
     typedef typename VecT<T>::type V;
-    const long stride = (long)gridDim.x * blockDim.x;
-    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < A.nvec; q += stride) {
+    // one thread per 16 bytes of every field, the whole grid in memory order (what a stream needs to reach
+    // ~6 TB/s here, tools/membench.hip); all loads of the thread are requested before the first store
+    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= A.nvec) return;
+    V a[NF], s[NF];
 #pragma unroll
-        for (int f = 0; f < NF; ++f) {
-            V a = ldv(A.x[f] + q * W);
-            const V s = ldv(A.s[f] + q * W);
+    for (int f = 0; f < NF; ++f) {
+        a[f] = ldv(A.x[f] + q * W);
+        s[f] = ldv(A.s[f] + q * W);
+    }
 #pragma unroll
-            for (int e = 0; e < W; ++e) a[e] = a[e] + A.dt * s[e];
-            stv(A.x[f] + q * W, a);
-        }
+    for (int f = 0; f < NF; ++f) {
+#pragma unroll
+        for (int e = 0; e < W; ++e) a[f][e] = a[f][e] + A.dt * s[f][e];
+        stv(A.x[f] + q * W, a[f]);
     }
 }
 
@@ -230,17 +235,20 @@ template <class T, int NF>
 __global__ void __launch_bounds__(256) add_source_bound_kernel(AddSourceBoundArgs<T, NF> A) {
     constexpr int W = VecT<T>::W;
     typedef typename VecT<T>::type V;
-    const long stride = (long)gridDim.x * blockDim.x;
-    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < A.nvec; q += stride) {
+    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= A.nvec) return;
+    V a[NF], s[NF];
 #pragma unroll
-        for (int f = 0; f < NF; ++f) {
-            V a = ldv(A.x[f] + q * W);
-            const V s = ldv(A.src[f] + q * W);
+    for (int f = 0; f < NF; ++f) {
+        a[f] = ldv(A.x[f] + q * W);
+        s[f] = ldv(A.src[f] + q * W);
+    }
 #pragma unroll
-            for (int e = 0; e < W; ++e) a[e] = a[e] + A.dt * s[e];
-            stv(A.x[f] + q * W, a);
-            stv(A.s_copy[f] + q * W, s);
-        }
+    for (int f = 0; f < NF; ++f) {
+#pragma unroll
+        for (int e = 0; e < W; ++e) a[f][e] = a[f][e] + A.dt * s[f][e];
+        stv(A.x[f] + q * W, a[f]);
+        stv(A.s_copy[f] + q * W, s[f]);
     }
 }
 
@@ -1070,11 +1078,14 @@ __global__ void __launch_bounds__(256) advect_kernel(Geom g, AdvectArgs<T, NF> A
     const int kg = g.kg0 + kl;
     T out[NF][W];
     bool bad = false;
+    // Phase 1: all W back-traces; phase 2: every gather of the thread (4 corner pairs x W cells x NF fields) is
+    // requested before the first one is consumed; phase 3: the interpolation. Cells past the row end (ragged last
+    // vector) trace from whatever the padding holds: the clamps and the NaN guard keep their addresses inside the
+    // buffer, their results are never stored and they cannot raise the halo flag.
+    T s1[W], t1[W], r1[W];
+    long p00[W];
 #pragma unroll
     for (int e = 0; e < W; ++e) {
-#pragma unroll
-        for (int f = 0; f < NF; ++f) out[f][e] = T(0);
-        if (e >= nv) continue;
         T x = (T)(i0 + e) - A.dt0 * uu[e];
         T y = (T)j - A.dt0 * vv[e];
         T z = (T)kg - A.dt0 * ww[e];
@@ -1090,28 +1101,36 @@ __global__ void __launch_bounds__(256) advect_kernel(Geom g, AdvectArgs<T, NF> A
         ia = ia < 0 ? 0 : (ia > N ? N : ia);
         ja = ja < 0 ? 0 : (ja > N ? N : ja);
         ka = ka < 0 ? 0 : (ka > N ? N : ka);
-        const T s1 = x - (T)ia, s0 = T(1) - s1;
-        const T t1 = y - (T)ja, t0 = T(1) - t1;
-        const T r1 = z - (T)ka, r0 = T(1) - r1;
+        s1[e] = x - (T)ia;
+        t1[e] = y - (T)ja;
+        r1[e] = z - (T)ka;
         int kla = ka - g.kg0;  // local plane of k0; k1 = kla + 1 must also be stored
         if (kla < 0 || kla > g.np - 2) {
-            bad = true;
+            bad |= (e < nv);
             kla = kla < 0 ? 0 : g.np - 2;
         }
-        const long p00 = row0(g, ja, kla) + ia;  // (i0,j0,k0)
-        const long p01 = p00 + g.plane;          // (i0,j0,k1)
-        const long p10 = p00 + g.px;             // (i0,j1,k0)
-        const long p11 = p10 + g.plane;          // (i0,j1,k1)
+        p00[e] = row0(g, ja, kla) + ia;  // (i0,j0,k0); +plane: k1; +px: j1
+    }
+    Pair C[NF][W][4];
+#pragma unroll
+    for (int e = 0; e < W; ++e)
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
             const T* __restrict__ d0 = A.d0[f];
             // the i0 / i0+1 samples are adjacent in memory: one element-aligned two-wide load per corner pair
-            const Pair c00 = *reinterpret_cast<const Pair*>(d0 + p00);
-            const Pair c01 = *reinterpret_cast<const Pair*>(d0 + p01);
-            const Pair c10 = *reinterpret_cast<const Pair*>(d0 + p10);
-            const Pair c11 = *reinterpret_cast<const Pair*>(d0 + p11);
-            out[f][e] = s0 * (t0 * (r0 * c00[0] + r1 * c01[0]) + t1 * (r0 * c10[0] + r1 * c11[0])) +
-                        s1 * (t0 * (r0 * c00[1] + r1 * c01[1]) + t1 * (r0 * c10[1] + r1 * c11[1]));
+            C[f][e][0] = *reinterpret_cast<const Pair*>(d0 + p00[e]);
+            C[f][e][1] = *reinterpret_cast<const Pair*>(d0 + p00[e] + g.plane);
+            C[f][e][2] = *reinterpret_cast<const Pair*>(d0 + p00[e] + g.px);
+            C[f][e][3] = *reinterpret_cast<const Pair*>(d0 + p00[e] + g.px + g.plane);
+        }
+#pragma unroll
+    for (int e = 0; e < W; ++e) {
+        const T s0 = T(1) - s1[e], t0 = T(1) - t1[e], r0 = T(1) - r1[e];
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+            const Pair c00 = C[f][e][0], c01 = C[f][e][1], c10 = C[f][e][2], c11 = C[f][e][3];
+            out[f][e] = s0 * (t0 * (r0 * c00[0] + r1[e] * c01[0]) + t1[e] * (r0 * c10[0] + r1[e] * c11[0])) +
+                        s1[e] * (t0 * (r0 * c00[1] + r1[e] * c01[1]) + t1[e] * (r0 * c10[1] + r1[e] * c11[1]));
         }
     }
     if (bad) atomicOr(A.flag, 1);
