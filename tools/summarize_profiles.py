@@ -18,6 +18,8 @@ os.makedirs(dst, exist_ok=True)
 shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, f"{tag}_bench.json"))
 for f in glob.glob(os.path.join(src, "bench_stats", "**", "*kernel_stats.csv"), recursive=True):
     shutil.copy(f, os.path.join(dst, f"{tag}_bench_kernel_stats.csv"))
+if os.path.exists(os.path.join(src, "rank_share.jsonl")):
+    shutil.copy(os.path.join(src, "rank_share.jsonl"), os.path.join(dst, f"{tag}_rank_share.jsonl"))
 
 
 def counters(path):
