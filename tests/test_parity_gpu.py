@@ -292,6 +292,68 @@ def test_slabs_stress_against_single_slab(N, P, K, prio, monkeypatch):
             assert_same(got[n], want[n], f"N={N} P={P} prio={prio} rep={rep}: {n}")
 
 
+@pytest.mark.parametrize("N,P,K,trap", [(128, 2, 20, "5"), (128, 4, 20, "3"), (160, 4, 12, "10"), (320, 2, 20, "5"),
+                                        (128, 2, 20, "0"), (64, 2, 9, "4")])
+def test_slabs_trapezoid_schedule(N, P, K, trap, monkeypatch):
+    """lin_solve on a decomposed grid: the boundary launch grows by two planes per pair so that consecutive interior
+    launches need no cross-stream wait (SF_TRAP pairs per block; 0 = off). Long solves (several blocks, a resync in
+    between, odd K, a row width that takes the overlapped mapping) must equal the single-slab GPU run bit for bit."""
+    dtype = np.float32
+    monkeypatch.setenv("SF_TRAP", trap)
+    f = small_velocity(rand_fields(N, dtype, 70 + P), N, dtype)
+
+    def run(nslabs):
+        with make(N, dtype, K=K, nslabs_local=nslabs) as fs:
+            for n in NAMES:
+                fs.upload(n, f[n])
+            fs.vel_step()
+            fs.dens_step()
+            fs.sync()
+            return {n: fs.download(n) for n in ("u", "v", "w", "dens")}
+
+    want = run(1)
+    for rep in range(2):
+        got = run(P)
+        for n in want:
+            assert_same(got[n], want[n], f"N={N} P={P} K={K} trap={trap} rep={rep}: {n}")
+
+
+@pytest.mark.parametrize("split", ["0", "2"])
+def test_diffuse_fields_together_or_one_by_one(split, monkeypatch):
+    """SF_SPLIT_FIELDS: u, v, w diffused in one three-field launch per pair or one field after the other."""
+    N, K, dtype = 40, 6, np.float32
+    monkeypatch.setenv("SF_SPLIT_FIELDS", split)
+    f = small_velocity(rand_fields(N, dtype, 91), N, dtype)
+    with make(N, dtype, K=K) as fs:
+        for n in NAMES:
+            fs.upload(n, f[n])
+        fs.vel_step()
+        fs.dens_step()
+        fs.sync()
+        got = {n: fs.download(n) for n in NAMES}
+    O.step(N, f, dtype(DT), dtype(DIFF), dtype(VISC), K)
+    for n in NAMES:
+        assert_same(got[n], f[n], f"split={split}: {n}")
+
+
+def test_loopback_rank_share_context():
+    """SF_FLAG_LOOPBACK_HALO (measurement aid): rank 1 of 4 without a communicator; the values next to the slab faces are
+    meaningless by construction, so this only checks that the context works, stays finite and reports the slab it
+    would own."""
+    N = 32
+    with S().FluidSolver(N, dtype="f32", iters=4, rank=1, nranks=4, flags=1) as fs:
+        assert fs.owned_planes() == (9, 17)
+        kb, ke = fs.stored_planes()
+        z = np.zeros((ke - kb, N + 2, N + 2), np.float32)
+        for n in NAMES:
+            fs.upload_planes(n, kb, z + (0.25 if n == "dens" else 0.0))
+        fs.vel_step()
+        fs.dens_step()
+        fs.sync()
+        d = fs.download_planes("dens", 9, 17)
+        assert np.isfinite(d).all()
+
+
 def test_upload_planes_fills_all_ghosts():
     """A rank that fills exactly sf_stored_planes() with sf_upload_planes gets the same state as sf_upload."""
     N, dtype, P = 16, np.float32, 4
