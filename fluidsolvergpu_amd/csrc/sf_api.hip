@@ -232,7 +232,8 @@ public:
         tx_override_ = env_int("SF_TX", 0);
         split_enabled_ = env_int("SF_SPLIT", 1) != 0;
         ovl_mode_ = env_int("SF_OVL", 1);
-        split_fields_ = env_int("SF_SPLIT_FIELDS", 1);  // 0 never, 1 when one field fits the Infinity Cache, 2 always
+        split_fields_ = env_int("SF_SPLIT_FIELDS", 1);
+        fuse_src_ = env_int("SF_FUSE_SRC", 1) != 0;  // fold add_source (bound sources) into diffuse's first sweep pair  // 0 never, 1 when one field fits the Infinity Cache, 2 always
         trap_m_ = env_int("SF_TRAP", 5);  // pairs per trapezoid block of a decomposed lin_solve (<= 1: off)
         strip_mode_ = env_int("SF_STRIP", 0);  // 0 heuristic, 1 dense, 2 wave-aligned row strips in the fused kernel
         graphs_ = env_int("SF_GRAPH", 0) != 0 && P_ == 1;
@@ -548,19 +549,19 @@ public:
     // SPEC §3 vel_step.
     void vel_step_body() {
         const int vel[3] = {SF_U, SF_V, SF_W}, vel0[3] = {SF_U0, SF_V0, SF_W0}, b123[3] = {1, 2, 3};
+        const T a = diffusion_a(visc_);
         if (bound_[0] >= 0 && bound_[1] >= 0 && bound_[2] >= 0) {
             const int src[3] = {bound_[0], bound_[1], bound_[2]};
-            op_add_source_bound<3>(vel, vel0, src);
+            op_diffuse_src<3>(vel, vel0, b123, src, a, T(1) + T(6) * a, K_);
         } else {
             for (int q = 0; q < 3; ++q)
                 if (bound_[q] >= 0) copy_field(vel0[q], bound_[q]);
             op_add_source<3>(vel, vel0);
+            swap_slots(SF_U0, SF_U);
+            swap_slots(SF_V0, SF_V);
+            swap_slots(SF_W0, SF_W);
+            op_lin_solve<3>(vel, vel0, b123, a, T(1) + T(6) * a, K_);
         }
-        swap_slots(SF_U0, SF_U);
-        swap_slots(SF_V0, SF_V);
-        swap_slots(SF_W0, SF_W);
-        const T a = diffusion_a(visc_);
-        op_lin_solve<3>(vel, vel0, b123, a, T(1) + T(6) * a, K_);
         op_project(SF_U, SF_V, SF_W, SF_U0, SF_V0);
         swap_slots(SF_U0, SF_U);
         swap_slots(SF_V0, SF_V);
@@ -572,15 +573,15 @@ public:
     // SPEC §3 dens_step.
     void dens_step_body() {
         const int x[1] = {SF_DENS}, x0[1] = {SF_DENS0}, b0[1] = {0};
+        const T a = diffusion_a(diff_);
         if (bound_[3] >= 0) {
             const int src[1] = {bound_[3]};
-            op_add_source_bound<1>(x, x0, src);
+            op_diffuse_src<1>(x, x0, b0, src, a, T(1) + T(6) * a, K_);
         } else {
             op_add_source<1>(x, x0);
+            swap_slots(SF_DENS0, SF_DENS);
+            op_lin_solve<1>(x, x0, b0, a, T(1) + T(6) * a, K_);
         }
-        swap_slots(SF_DENS0, SF_DENS);
-        const T a = diffusion_a(diff_);
-        op_lin_solve<1>(x, x0, b0, a, T(1) + T(6) * a, K_);
         swap_slots(SF_DENS0, SF_DENS);
         op_advect<1>(x, x0, b0, SF_U, SF_V, SF_W);
     }
@@ -1141,7 +1142,7 @@ private:
         return B;
     }
 
-    template <int NF, bool NT, int RJ, int RK>
+    template <int NF, bool NT, int RJ, int RK, bool SRC = false>
     void launch_fused2(Slab& sl, const sfk::JacobiArgs<T, NF>& A, int kb, int ke, bool first, bool last) {
         const int nvec = N_ / W;
         sfk::TileMap m{};
@@ -1175,22 +1176,26 @@ private:
         const long nblocks = per_plane * ceil_div(ke - kb, RK) * NF;
         const bool xlds = m.strip % 64 != 0 && 64 % m.strip != 0;
         const unsigned nb = (unsigned)nblocks;
-        if (ovl) {
-            if (NF == 1 && x_is_zero_)
-                launch_k(sl, sfk::jacobi2_kernel<T, 1, NT, RJ, RK, false, true, true>, nb, 256u, sl.geom, first_field(A), kb,
-                         ke, m);
-            else
-                launch_k(sl, sfk::jacobi2_kernel<T, NF, NT, RJ, RK, false, false, true>, nb, 256u, sl.geom, A, kb, ke, m);
-        } else if (NF == 1 && x_is_zero_) {
-            if (xlds)
-                launch_k(sl, sfk::jacobi2_kernel<T, 1, NT, RJ, RK, true, true>, nb, 256u, sl.geom, first_field(A), kb, ke, m);
-            else
-                launch_k(sl, sfk::jacobi2_kernel<T, 1, NT, RJ, RK, false, true>, nb, 256u, sl.geom, first_field(A), kb, ke, m);
-        } else if (xlds) {
-            launch_k(sl, sfk::jacobi2_kernel<T, NF, NT, RJ, RK, true>, nb, 256u, sl.geom, A, kb, ke, m);
-        } else {
-            launch_k(sl, sfk::jacobi2_kernel<T, NF, NT, RJ, RK, false>, nb, 256u, sl.geom, A, kb, ke, m);
+        if constexpr (!SRC) {
+            if (NF == 1 && x_is_zero_) {  // implicit-zero first pair of project's lin_solve
+                if (ovl)
+                    launch_k(sl, sfk::jacobi2_kernel<T, 1, NT, RJ, RK, false, true, true>, nb, 256u, sl.geom, first_field(A),
+                             kb, ke, m);
+                else if (xlds)
+                    launch_k(sl, sfk::jacobi2_kernel<T, 1, NT, RJ, RK, true, true>, nb, 256u, sl.geom, first_field(A), kb, ke,
+                             m);
+                else
+                    launch_k(sl, sfk::jacobi2_kernel<T, 1, NT, RJ, RK, false, true>, nb, 256u, sl.geom, first_field(A), kb,
+                             ke, m);
+                return;
+            }
         }
+        if (ovl)
+            launch_k(sl, sfk::jacobi2_kernel<T, NF, NT, RJ, RK, false, false, true, SRC>, nb, 256u, sl.geom, A, kb, ke, m);
+        else if (xlds)
+            launch_k(sl, sfk::jacobi2_kernel<T, NF, NT, RJ, RK, true, false, false, SRC>, nb, 256u, sl.geom, A, kb, ke, m);
+        else
+            launch_k(sl, sfk::jacobi2_kernel<T, NF, NT, RJ, RK, false, false, false, SRC>, nb, 256u, sl.geom, A, kb, ke, m);
     }
 
     // LDS-staged marching form: rows of up to 128 vectors (blockDim = NV x 4 <= 512 threads).
@@ -1218,11 +1223,11 @@ private:
                            sl.geom, A, kb, ke, m, kc);
     }
 
-    template <int NF>
+    template <int NF, bool SRC = false>
     void launch_jacobi2(Slab& sl, const sfk::JacobiArgs<T, NF>& A, int kb, int ke, bool first, bool last) {
         const bool nt = nt_mode_ == 1 ||
                         (nt_mode_ == 2 && (size_t)field_elems_ * sizeof(T) * 3 * NF > ((size_t)384 << 20));
-        if (can_march2() && !x_is_zero_) {  // the implicit-zero first pair only exists in the register kernel
+        if (can_march2() && !x_is_zero_ && !SRC) {  // implicit-zero / source pairs only exist in the register kernel
             if (nt)
                 launch_march2<NF, true>(sl, A, kb, ke, first, last);
             else
@@ -1230,21 +1235,21 @@ private:
             return;
         }
         if (nt)
-            launch_fused2_shape<NF, true>(sl, A, kb, ke, first, last);
+            launch_fused2_shape<NF, true, SRC>(sl, A, kb, ke, first, last);
         else
-            launch_fused2_shape<NF, false>(sl, A, kb, ke, first, last);
+            launch_fused2_shape<NF, false, SRC>(sl, A, kb, ke, first, last);
     }
 
-    template <int NF, bool NT>
+    template <int NF, bool NT, bool SRC = false>
     void launch_fused2_shape(Slab& sl, const sfk::JacobiArgs<T, NF>& A, int kb, int ke, bool first, bool last) {
         // 2x2 output vectors per thread: measured best of 1x1, 2x1, 1x2, 2x2, 4x2 (4x2 spills)
-        launch_fused2<NF, NT, 2, 2>(sl, A, kb, ke, first, last);
+        launch_fused2<NF, NT, 2, 2, SRC>(sl, A, kb, ke, first, last);
     }
 
     // K Jacobi sweeps on NF fields at once; scratch buffers are swapped into the slots.
     template <int NF>
     void op_lin_solve(const int (&x)[NF], const int (&x0)[NF], const int (&b)[NF], T a, T c, int K,
-                      bool x_zero = false) {
+                      bool x_zero = false, bool continued = false) {
         static_assert(NF <= NSCRATCH, "not enough scratch buffers");
         if constexpr (NF > 1) {
             // x, x0 and x' of ONE field fit the 256 MiB Infinity Cache where those of NF fields together do not:
@@ -1255,7 +1260,7 @@ private:
             if (split_fields_ == 2 || (split_fields_ == 1 && fits)) {
                 for (int f = 0; f < NF; ++f) {
                     const int xf[1] = {x[f]}, x0f[1] = {x0[f]}, bf[1] = {b[f]};
-                    op_lin_solve<1>(xf, x0f, bf, a, c, K, x_zero);
+                    op_lin_solve<1>(xf, x0f, bf, a, c, K, x_zero, continued);
                 }
                 return;
             }
@@ -1293,9 +1298,9 @@ private:
                 A.a = a;
                 A.inv = inv;
                 if (pair)
-                    launch_jacobi2<NF>(sl, A, kb, ke, it == 0, it + step == K);
+                    launch_jacobi2<NF>(sl, A, kb, ke, it == 0 && !continued, it + step == K);
                 else
-                    launch_jacobi<NF>(sl, A, kb, ke, it == 0, it + step == K);
+                    launch_jacobi<NF>(sl, A, kb, ke, it == 0 && !continued, it + step == K);
             }, step, jacobi_mode_ != 0);
             // the new iterate becomes the field; the old buffer becomes scratch
             for (Slab& sl : slabs_)
@@ -1305,6 +1310,57 @@ private:
         }
         trap_extra_ = 0;
         x_is_zero_ = false;
+    }
+
+    // diffuse with add_source folded in (sources bound to resident slots): replaces
+    //     add_source_bound(x, x0 <- src); swap(x0, x); lin_solve(x, x0)
+    // The first sweep pair reads the source as its iterate and the field before add_source, forms x + dt*src in
+    // registers and stores it to the x0 slot's buffer (whose old content is dead) for the later pairs. One pass
+    // over the arrays less per field. Single slab only: the right-hand side is stored on interior planes, a
+    // decomposed grid would need it on the first ghost plane as well.
+    template <int NF>
+    void op_diffuse_src(const int (&x)[NF], const int (&x0)[NF], const int (&b)[NF], const int (&src)[NF], T a, T c,
+                        int K) {
+        if (!(fuse_src_ && P_ == 1 && can_fuse2() && !can_march2() && K >= 2)) {
+            op_add_source_bound<NF>(x, x0, src);
+            for (int f = 0; f < NF; ++f) swap_slots(x0[f], x[f]);
+            op_lin_solve<NF>(x, x0, b, a, c, K);
+            return;
+        }
+        if constexpr (NF > 1) {
+            const double one = 3.0 * (double)(N_ + 2) * (N_ + 2) * nplanes_ * sizeof(T);
+            if (split_fields_ == 2 || (split_fields_ == 1 && one <= 0.9 * 256.0 * 1048576.0)) {
+                for (int f = 0; f < NF; ++f) {
+                    const int xf[1] = {x[f]}, x0f[1] = {x0[f]}, bf[1] = {b[f]}, sf[1] = {src[f]};
+                    op_diffuse_src<1>(xf, x0f, bf, sf, a, c, K);
+                }
+                return;
+            }
+        }
+        const T inv = T(1) / c;
+        for (Slab& sl : slabs_)
+            for (int f = 0; f < NF; ++f) {
+                ensure(sl, x[f]);
+                ensure(sl, x0[f]);
+                ensure(sl, src[f]);
+            }
+        for_planes([&](Slab& sl, int kb, int ke) {
+            sfk::JacobiArgs<T, NF> A;
+            for (int f = 0; f < NF; ++f) {
+                A.x[f] = sl.field[src[f]];    // iterate = the source (Stam's initial guess)
+                A.x0[f] = sl.field[x[f]];     // the field before add_source
+                A.xn[f] = sl.scratch[f];
+                A.x0out[f] = sl.field[x0[f]];  // right-hand side x + dt*src for the later pairs
+                A.b[f] = b[f];
+            }
+            A.a = a;
+            A.inv = inv;
+            A.dt = dt_;
+            launch_jacobi2<NF, true>(sl, A, kb, ke, true, K == 2);
+        }, 2, true);
+        for (Slab& sl : slabs_)
+            for (int f = 0; f < NF; ++f) std::swap(sl.field[x[f]], sl.scratch[f]);
+        op_lin_solve<NF>(x, x0, b, a, c, K - 2, false, true);
     }
 
     template <int NF>
@@ -1405,7 +1461,7 @@ private:
     T dt_{}, diff_{}, visc_{};
     int num_cu_ = 256;
     int nzl_ = 0, lead_ = 0, px_ = 0, nplanes_ = 0, kchunk_ = 0, jacobi_mode_ = 2, tx_override_ = 0, nt_mode_ = 2, rb_shape_ = 0;
-    bool ishell_skip_ = true, advect_lds_ = false, zero_skip_ = true, x_is_zero_ = false;
+    bool ishell_skip_ = true, advect_lds_ = false, zero_skip_ = true, x_is_zero_ = false, fuse_src_ = true;
     int fuse2_ = 1, kc2_ = 32;
     long plane_ = 0, field_elems_ = 0;
     std::vector<Slab> slabs_;

@@ -264,6 +264,11 @@ struct JacobiArgs {
     T* xn[NF];
     int b[NF];
     T a, inv;
+    // jacobi2_kernel<..., SRC = true> only (add_source folded into the first sweep pair of diffuse): x is the
+    // source s (Stam's initial guess), x0 is the field BEFORE add_source, the right-hand side x0 + dt*s is formed in
+    // registers and stored to x0out for the later pairs
+    T* x0out[NF];
+    T dt;
 };
 
 template <class T, int NF>
@@ -574,10 +579,16 @@ __global__ void __launch_bounds__(256) jacobi_rb_kernel(Geom g, JacobiArgs<T, NF
 #endif
 constexpr int SF_OVL_OUT = SF_OVL_OUT_N;
 constexpr int SF_OVL_LO = (64 - SF_OVL_OUT_N) / 2;  // first output lane
-template <class T, int NF, bool NT, int RJ, int RK, bool XLDS, bool XZ = false, bool OVL = false>
+// SRC: the first pair of diffuse with add_source folded in. `x` is the source array s, `x0` the field before
+// add_source; the right-hand side rhs = x0 + dt*s (the expression of add_source_kernel) is formed in registers at
+// the 12 positions the first sweep needs — s there is already held as x — and stored at the thread's own output
+// positions to `x0out`, where the later pairs read it. Saves the add_source pass (4 words per cell) for one extra
+// word written here. Only interior cells of rhs are stored: lin_solve never reads rhs on the shell.
+template <class T, int NF, bool NT, int RJ, int RK, bool XLDS, bool XZ = false, bool OVL = false, bool SRC = false>
 __global__ void __launch_bounds__(256, SF_J2_WAVES) jacobi2_kernel(Geom g, JacobiArgs<T, NF> A, int kb, int ke,
                                                        TileMap m) {
     static_assert(!(OVL && XLDS), "the overlapped mapping has no seams");
+    static_assert(!(SRC && XZ), "a source pair has a non-zero iterate");
     constexpr int W = VecT<T>::W;
     typedef typename VecT<T>::type V;
     constexpr int NPOS = RJ * RK;
@@ -639,6 +650,7 @@ __global__ void __launch_bounds__(256, SF_J2_WAVES) jacobi2_kernel(Geom g, Jacob
     const T* __restrict__ x = A.x[0];
     const T* __restrict__ x0 = A.x0[0];
     T* __restrict__ xn = A.xn[0];
+    T* __restrict__ x0out = A.x0out[0];
     int b = A.b[0];
 #pragma unroll
     for (int ff = 1; ff < NF; ++ff)
@@ -646,6 +658,7 @@ __global__ void __launch_bounds__(256, SF_J2_WAVES) jacobi2_kernel(Geom g, Jacob
             x = A.x[ff];
             x0 = A.x0[ff];
             xn = A.xn[ff];
+            x0out = A.x0out[ff];
             b = A.b[ff];
         }
     const T sx = (b == 1) ? T(-1) : T(1);
@@ -689,6 +702,18 @@ __global__ void __launch_bounds__(256, SF_J2_WAVES) jacobi2_kernel(Geom g, Jacob
 #pragma unroll
         for (int r = -1; r <= RJ; ++r)
             if (SF_DIST(c, RK) + SF_DIST(r, RJ) <= 1) S[c + 1][r + 1] = ldv(x0 + planeq[c + 2] + rowq[r + 2]);
+    if (SRC) {
+        const T dt = A.dt;
+#pragma unroll
+        for (int c = -1; c <= RK; ++c)
+#pragma unroll
+            for (int r = -1; r <= RJ; ++r)
+                if (SF_DIST(c, RK) + SF_DIST(r, RJ) <= 1) {
+#pragma unroll
+                    for (int e = 0; e < W; ++e)
+                        S[c + 1][r + 1][e] = S[c + 1][r + 1][e] + dt * X[c + 2][r + 2][e];  // add_source: x + dt*s
+                }
+    }
 
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -827,6 +852,7 @@ __global__ void __launch_bounds__(256, SF_J2_WAVES) jacobi2_kernel(Geom g, Jacob
                 __builtin_nontemporal_store(o, reinterpret_cast<V*>(xn + q));
             else
                 stv(xn + q, o);
+            if (SRC) stv(x0out + q, s);
             emit_shells<T, W>(xn, g, b, i0, j, kl, out, W, m.ishell_write != 0);
         }
     }

@@ -475,10 +475,16 @@ def test_snapshot_is_a_consistent_async_copy(P):
         assert_same(result[n], f[n], f"snapshot {n}")
 
 
-@pytest.mark.parametrize("P", [1, 2])
-def test_bound_sources(P):
-    """sf_bind_sources == copying the user slots into u0/v0/w0/dens0 before every step, bit for bit."""
-    N, dtype, K = 24, np.float32, 5
+@pytest.mark.parametrize("fuse", ["1", "0"])
+@pytest.mark.parametrize("N,K,dtype,P", [(24, 5, np.float32, 1), (24, 5, np.float32, 2), (40, 2, np.float32, 1),
+                                          (40, 3, np.float64, 1), (100, 6, np.float32, 1), (64, 4, np.float64, 1),
+                                          (128, 7, np.float32, 1), (136, 4, np.float32, 1), (8, 4, np.float32, 1),
+                                          (6, 1, np.float32, 1), (256, 4, np.float32, 1), (64, 6, np.float32, 4)])
+def test_bound_sources(N, K, dtype, P, fuse, monkeypatch):
+    """sf_bind_sources == copying the user slots into u0/v0/w0/dens0 before every step, bit for bit — with add_source
+    folded into the first sweep pair of diffuse (SF_FUSE_SRC=1, single slab) and as a separate pass."""
+    monkeypatch.setenv("SF_FUSE_SRC", fuse)
+    steps = 3 if N <= 64 else 2
     f = small_velocity(rand_fields(N, dtype, 70), N, dtype)
     src = {"u0": f["u0"].copy(), "v0": f["v0"].copy(), "w0": f["w0"].copy(), "dens0": f["dens0"].copy()}
     with make(N, dtype, K=K, nslabs_local=P) as fs:
@@ -487,18 +493,18 @@ def test_bound_sources(P):
         for slot, n in (("user0", "u0"), ("user1", "v0"), ("user2", "w0"), ("user3", "dens0")):
             fs.upload(slot, src[n])
         fs.bind_sources("user0", "user1", "user2", "user3")
-        for _ in range(3):
+        for _ in range(steps):
             fs.vel_step()
             fs.dens_step()
         fs.sync()
         got = {n: fs.download(n) for n in NAMES}
         assert_same(fs.download("user1"), src["v0"], "bound source slot must stay untouched")
-    for _ in range(3):
+    for _ in range(steps):
         for n in src:
             f[n][...] = src[n]
         O.step(N, f, dtype(DT), dtype(DIFF), dtype(VISC), K)
     for n in NAMES:
-        assert_same(got[n], f[n], f"bound sources P={P}: {n}")
+        assert_same(got[n], f[n], f"bound sources N={N} K={K} P={P} fuse={fuse}: {n}")
 
 
 def test_graph_replay_matches(monkeypatch):
