@@ -1316,12 +1316,13 @@ private:
     //     add_source_bound(x, x0 <- src); swap(x0, x); lin_solve(x, x0)
     // The first sweep pair reads the source as its iterate and the field before add_source, forms x + dt*src in
     // registers and stores it to the x0 slot's buffer (whose old content is dead) for the later pairs. One pass
-    // over the arrays less per field. Single slab only: the right-hand side is stored on interior planes, a
-    // decomposed grid would need it on the first ghost plane as well.
+    // over the arrays less per field. The pair stores the right-hand side on the planes it computes; on a
+    // decomposed grid the later pairs also read it on the first ghost plane of either side, which a small launch
+    // fills from the (current) ghost planes of x and src.
     template <int NF>
     void op_diffuse_src(const int (&x)[NF], const int (&x0)[NF], const int (&b)[NF], const int (&src)[NF], T a, T c,
                         int K) {
-        if (!(fuse_src_ && P_ == 1 && can_fuse2() && !can_march2() && K >= 2)) {
+        if (!(fuse_src_ && can_fuse2() && !can_march2() && K >= 2)) {
             op_add_source_bound<NF>(x, x0, src);
             for (int f = 0; f < NF; ++f) swap_slots(x0[f], x[f]);
             op_lin_solve<NF>(x, x0, b, a, c, K);
@@ -1358,8 +1359,31 @@ private:
             A.dt = dt_;
             launch_jacobi2<NF, true>(sl, A, kb, ke, true, K == 2);
         }, 2, true);
+        if (P_ > 1) {
+            // right-hand side on the ghost planes G-1 and G+nzl. It reads ghost planes of x, so it must follow the
+            // last halo: on the boundary stream when for_planes ran its two-stream schedule (bs waits for every halo
+            // and the next boundary launch follows in stream order), on the compute stream otherwise (for_planes
+            // has just joined it)
+            const bool two = split_enabled_ && nzl_ > 2 * std::max(2, G_);
+            for (Slab& sl : slabs_) {
+                sfk::RhsPlanesArgs<T, NF> R;
+                for (int f = 0; f < NF; ++f) {
+                    R.out[f] = sl.field[x0[f]];
+                    R.a[f] = sl.field[x[f]];
+                    R.s[f] = sl.field[src[f]];
+                }
+                R.dt = dt_;
+                R.off[0] = (long)(G_ - 1) * plane_;
+                R.off[1] = (long)(G_ + nzl_) * plane_;
+                R.nvec = plane_ / W;
+                hipLaunchKernelGGL((sfk::rhs_planes_kernel<T, NF>), dim3((unsigned)ceil_div(R.nvec, 256L), 2), dim3(256), 0,
+                                   two ? sl.bs : sl.cs, R);
+            }
+            SF_HIP(hipGetLastError());
+        }
         for (Slab& sl : slabs_)
             for (int f = 0; f < NF; ++f) std::swap(sl.field[x[f]], sl.scratch[f]);
+        exchange<NF>(x);
         op_lin_solve<NF>(x, x0, b, a, c, K - 2, false, true);
     }
 

@@ -252,6 +252,35 @@ __global__ void __launch_bounds__(256) add_source_bound_kernel(AddSourceBoundArg
     }
 }
 
+// out = a + dt*s on up to two plane ranges (the add_source expression): the right-hand side of a folded
+// add_source on the ghost planes next to a slab, which the source pair itself does not store.
+template <class T, int NF>
+struct RhsPlanesArgs {
+    T* out[NF];
+    const T* a[NF];
+    const T* s[NF];
+    T dt;
+    long off[2];  // element offset of each range
+    long nvec;    // vectors per range
+};
+
+template <class T, int NF>
+__global__ void __launch_bounds__(256) rhs_planes_kernel(RhsPlanesArgs<T, NF> A) {
+    constexpr int W = VecT<T>::W;
+    typedef typename VecT<T>::type V;
+    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= A.nvec) return;
+    const long p = A.off[blockIdx.y] + q * W;
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+        V a = ldv(A.a[f] + p);
+        const V s = ldv(A.s[f] + p);
+#pragma unroll
+        for (int e = 0; e < W; ++e) a[e] = a[e] + A.dt * s[e];
+        stv(A.out[f] + p, a);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // lin_solve: one Jacobi sweep + fused set_bnd (SPEC §3 lin_solve). Algorithmic traffic 3 words
 // per cell (read x, read x0, write x'). Each thread owns a W-wide column piece and marches kchunk

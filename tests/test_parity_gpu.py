@@ -479,7 +479,9 @@ def test_snapshot_is_a_consistent_async_copy(P):
 @pytest.mark.parametrize("N,K,dtype,P", [(24, 5, np.float32, 1), (24, 5, np.float32, 2), (40, 2, np.float32, 1),
                                           (40, 3, np.float64, 1), (100, 6, np.float32, 1), (64, 4, np.float64, 1),
                                           (128, 7, np.float32, 1), (136, 4, np.float32, 1), (8, 4, np.float32, 1),
-                                          (6, 1, np.float32, 1), (256, 4, np.float32, 1), (64, 6, np.float32, 4)])
+                                          (6, 1, np.float32, 1), (256, 4, np.float32, 1), (64, 6, np.float32, 4),
+                                          (128, 20, np.float32, 2), (160, 6, np.float32, 4), (64, 5, np.float64, 2),
+                                          (16, 4, np.float32, 8), (16, 4, np.float32, 4)])
 def test_bound_sources(N, K, dtype, P, fuse, monkeypatch):
     """sf_bind_sources == copying the user slots into u0/v0/w0/dens0 before every step, bit for bit — with add_source
     folded into the first sweep pair of diffuse (SF_FUSE_SRC=1, single slab) and as a separate pass."""
