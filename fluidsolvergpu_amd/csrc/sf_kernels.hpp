@@ -712,49 +712,20 @@ __global__ void __launch_bounds__(256, SF_J2_WAVES) jacobi2_kernel(Geom g, Jacob
     // distance of block-local coordinate a in [-2, R+1] from the output range [0, R-1]
 #define SF_DIST(a_, R_) ((a_) < 0 ? -(a_) : ((a_) > (R_)-1 ? (a_) - ((R_)-1) : 0))
 
-    V X[RK + 4][RJ + 4];
-#pragma unroll
-    for (int c = -2; c <= RK + 1; ++c)
-#pragma unroll
-        for (int r = -2; r <= RJ + 1; ++r)
-            if (SF_DIST(c, RK) + SF_DIST(r, RJ) <= 2) {
-                if (XZ) {
-#pragma unroll
-                    for (int e = 0; e < W; ++e) X[c + 2][r + 2][e] = T(0);
-                } else {
-                    X[c + 2][r + 2] = ldv(x + planeq[c + 2] + rowq[r + 2]);
-                }
-            }
-    V S[RK + 2][RJ + 2];
-#pragma unroll
-    for (int c = -1; c <= RK; ++c)
-#pragma unroll
-        for (int r = -1; r <= RJ; ++r)
-            if (SF_DIST(c, RK) + SF_DIST(r, RJ) <= 1) S[c + 1][r + 1] = ldv(x0 + planeq[c + 2] + rowq[r + 2]);
-    if (SRC) {
-        const T dt = A.dt;
-#pragma unroll
-        for (int c = -1; c <= RK; ++c)
-#pragma unroll
-            for (int r = -1; r <= RJ; ++r)
-                if (SF_DIST(c, RK) + SF_DIST(r, RJ) <= 1) {
-#pragma unroll
-                    for (int e = 0; e < W; ++e)
-                        S[c + 1][r + 1][e] = S[c + 1][r + 1][e] + dt * X[c + 2][r + 2][e];  // add_source: x + dt*s
-                }
-    }
-
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const bool first_vec = (vec == 0), last_vec = (vec == nvec - 1);
     // neighbour vector lives in the same wave (always, for the lanes that matter, in the overlapped mapping)
     const bool has_left = OVL || lane != 0, has_right = OVL || lane != 63;
-
     const bool multi_wave = !OVL && (64 % m.strip) != 0;  // some row crosses a wave boundary
+
+    // ---- every load of the thread is requested here, before the first use, in the order the first sweep consumes
+    // them (loads complete in order): end cells, right-hand sides, then the x vectors position by position, so the
+    // arithmetic of the first positions overlaps the flight of the later vectors.
     // End cells of x that no lane of this wave holds (the i-shell cells of caller data in a first sweep; the cell
-    // across a wave seam when seams are not handed over through LDS): all of them are requested HERE, back to back
-    // with the vector loads above. Loading each one where it is used costs a dependent memory round trip per
-    // first-sweep position (12 in a row: the compiler cannot hoist a load out of its divergent branch).
+    // across a wave seam when seams are not handed over through LDS). Loading each one where it is used costs a
+    // dependent memory round trip per first-sweep position (12 in a row: the compiler cannot hoist a load out of
+    // its divergent branch).
     const bool left_mem = !XZ && (first_vec ? m.ishell_mem != 0 : (!has_left && !XLDS));
     const bool right_mem = !XZ && (last_vec ? m.ishell_mem != 0 : (!has_right && !XLDS));
     T XL[NYPOS], XR[NYPOS];
@@ -775,6 +746,48 @@ __global__ void __launch_bounds__(256, SF_J2_WAVES) jacobi2_kernel(Geom g, Jacob
             for (int r = -1; r <= RJ; ++r)
                 if (SF_DIST(c, RK) + SF_DIST(r, RJ) <= 1)
                     XR[(c + 1) * (RJ + 2) + (r + 1)] = x[planeq[c + 2] + rowq[r + 2] + W];
+    }
+    V S[RK + 2][RJ + 2];
+#pragma unroll
+    for (int c = -1; c <= RK; ++c)
+#pragma unroll
+        for (int r = -1; r <= RJ; ++r)
+            if (SF_DIST(c, RK) + SF_DIST(r, RJ) <= 1) S[c + 1][r + 1] = ldv(x0 + planeq[c + 2] + rowq[r + 2]);
+    V X[RK + 4][RJ + 4];
+    {
+        bool have[RK + 4][RJ + 4] = {};  // resolved at compile time after unrolling
+#pragma unroll
+        for (int c = -1; c <= RK; ++c)
+#pragma unroll
+            for (int r = -1; r <= RJ; ++r) {
+                if (SF_DIST(c, RK) + SF_DIST(r, RJ) > 1) continue;
+#pragma unroll
+                for (int t = 0; t < 5; ++t) {  // the stencil of first-sweep position (c, r)
+                    const int cc = c + (t == 1 ? -1 : (t == 2 ? 1 : 0)), rr = r + (t == 3 ? -1 : (t == 4 ? 1 : 0));
+                    if (have[cc + 2][rr + 2]) continue;
+                    have[cc + 2][rr + 2] = true;
+                    if (XZ) {
+#pragma unroll
+                        for (int e = 0; e < W; ++e) X[cc + 2][rr + 2][e] = T(0);
+                    } else {
+                        X[cc + 2][rr + 2] = ldv(x + planeq[cc + 2] + rowq[rr + 2]);
+                    }
+                }
+            }
+    }
+    // nothing below may be scheduled above this point and no load below it: all requests are out before any use
+    __builtin_amdgcn_sched_barrier(0);
+    if (SRC) {
+        const T dt = A.dt;
+#pragma unroll
+        for (int c = -1; c <= RK; ++c)
+#pragma unroll
+            for (int r = -1; r <= RJ; ++r)
+                if (SF_DIST(c, RK) + SF_DIST(r, RJ) <= 1) {
+#pragma unroll
+                    for (int e = 0; e < W; ++e)
+                        S[c + 1][r + 1][e] = S[c + 1][r + 1][e] + dt * X[c + 2][r + 2][e];  // add_source: x + dt*s
+                }
     }
     // ---- x end cells cross waves through LDS (cheaper than two masked per-lane loads per position) ---------
     if (XLDS && !XZ && multi_wave) {
