@@ -935,8 +935,8 @@ private:
 
     // Kernel launch on sl.cur.
     template <class F, class... Args>
-    void launch_k(Slab& sl, F kernel, unsigned nblocks, unsigned nthreads, Args... args) {
-        hipLaunchKernelGGL(kernel, dim3(nblocks), dim3(nthreads), 0, sl.cur, args...);
+    void launch_k(Slab& sl, F kernel, dim3 nblocks, unsigned nthreads, Args... args) {
+        hipLaunchKernelGGL(kernel, nblocks, dim3(nthreads), 0, sl.cur, args...);
     }
 
     // Halo exchange of NF fields: first / last interior plane -> neighbour's ghost plane.
@@ -1172,10 +1172,11 @@ private:
             m.gy = ceil_div(ceil_div(items, sfk::SF_OVL_OUT), 4);
             m.band = (jacobi_mode_ >= 2 && m.gy >= 16) ? ceil_div(m.gy, 8) : 0;
         }
-        const long per_plane = m.band > 0 ? (long)m.nxcd * m.band : (long)m.gy;
-        const long nblocks = per_plane * ceil_div(ke - kb, RK) * NF;
+        m.strip_shift = (m.strip & (m.strip - 1)) == 0 ? __builtin_ctz((unsigned)m.strip) : -1;
+        m.nvec_magic = nvec > 1 ? 0xFFFFFFFFu / (unsigned)nvec + 1u : 0u;
+        const dim3 nb(m.band > 0 ? (unsigned)m.nxcd : (unsigned)m.gy, m.band > 0 ? (unsigned)m.band : 1u,
+                      (unsigned)(ceil_div(ke - kb, RK) * NF));
         const bool xlds = m.strip % 64 != 0 && 64 % m.strip != 0;
-        const unsigned nb = (unsigned)nblocks;
         if constexpr (!SRC) {
             if (NF == 1 && x_is_zero_) {  // implicit-zero first pair of project's lin_solve
                 if (ovl)

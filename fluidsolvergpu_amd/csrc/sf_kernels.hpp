@@ -368,6 +368,8 @@ struct TileMap {
     int rows;   // jacobi2_kernel: row strips per workgroup
     int strip;  // jacobi2_kernel: lanes reserved per strip (>= N/W; N/W itself packs strips densely, a multiple of
                 // 64 keeps every strip aligned to wave boundaries at the price of idle lanes)
+    int strip_shift;       // log2(strip) when strip is a power of two, else -1 (spares the kernel a division)
+    unsigned nvec_magic;   // floor(2^32 / (N/W)) + 1: t / (N/W) == umulhi(t, magic) for the t < 2^16 of the OVL mapping
 };
 
 __device__ __forceinline__ int plane_of(const TileMap& m, int kb, int t) {
@@ -626,21 +628,19 @@ __global__ void __launch_bounds__(256, SF_J2_WAVES) jacobi2_kernel(Geom g, Jacob
     __shared__ T sh_last[4][NPOS];     //                          y of the wave's last cell
     __shared__ T shx_first[4][NYPOS];  // [wave][first-sweep position]: x of the wave's first / last cell
     __shared__ T shx_last[4][NYPOS];
+    // 3-D grid (x fastest in dispatch order, so workgroup x of a banded launch runs on XCD x): x = XCD group (or the
+    // j-tile when not banded), y = j-tile inside the band, z = plane block (+ field). No division to decode.
     int jt, kk, f;
     {
-        int r = (int)blockIdx.x;
-        if (m.band > 0) {
-            const int xcd = r % m.nxcd;
-            r /= m.nxcd;
-            jt = xcd * m.band + r % m.band;
-            r /= m.band;
+        jt = m.band > 0 ? (int)blockIdx.x * m.band + (int)blockIdx.y : (int)blockIdx.x;
+        if (NF == 1) {
+            kk = (int)blockIdx.z;
+            f = 0;
         } else {
-            jt = r % m.gy;
-            r /= m.gy;
+            const int nkg = (ke - kb + RK - 1) / RK;
+            kk = (int)blockIdx.z % nkg;
+            f = (int)blockIdx.z / nkg;
         }
-        const int nkg = (ke - kb + RK - 1) / RK;
-        kk = r % nkg;
-        f = r / nkg;
     }
     const int N = g.N;
     const int nvec = N / W;
@@ -661,11 +661,11 @@ __global__ void __launch_bounds__(256, SF_J2_WAVES) jacobi2_kernel(Geom g, Jacob
         int t = (jt * 4 + (tid >> 6)) * SF_OVL_OUT + (tid & 63) - SF_OVL_LO;
         active = t >= 0 && t < total && (tid & 63) >= SF_OVL_LO && (tid & 63) < SF_OVL_LO + SF_OVL_OUT;
         t = t < 0 ? 0 : (t >= total ? total - 1 : t);  // feeder / padding lanes run on valid addresses
-        const int rg = t / nvec;
+        const int rg = nvec == 1 ? t : (int)__umulhi((unsigned)t, m.nvec_magic);  // t / nvec
         vec = t - rg * nvec;
         j0 = 1 + rg * RJ;
     } else {
-        const int strip = tid / m.strip;
+        const int strip = m.strip_shift >= 0 ? (tid >> m.strip_shift) : tid / m.strip;
         vec = tid - strip * m.strip;
         j0 = 1 + (jt * m.rows + strip) * RJ;
         active = tile_ok && strip < m.rows && vec < nvec && j0 <= N;
