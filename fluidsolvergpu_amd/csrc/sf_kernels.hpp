@@ -702,13 +702,13 @@ __global__ void __launch_bounds__(256, SF_J2_WAVES) jacobi2_kernel(Geom g, Jacob
         j = j < 0 ? 0 : (j > N + 1 ? N + 1 : j);
         rowq[r] = (long)j * g.px + (g.lead - 1) + i0;
     }
+    // (one 64-bit multiply for plane k0, then clamped steps of one plane: the stored range is [0, np-1])
     long planeq[RK + 4];
+    planeq[2] = (long)k0 * g.plane;
 #pragma unroll
-    for (int r = 0; r < RK + 4; ++r) {
-        int kl = k0 - 2 + r;
-        kl = kl < 0 ? 0 : (kl > g.np - 1 ? g.np - 1 : kl);
-        planeq[r] = (long)kl * g.plane;
-    }
+    for (int r = 1; r >= 0; --r) planeq[r] = planeq[r + 1] - ((k0 - 2 + r >= 0) ? g.plane : 0L);
+#pragma unroll
+    for (int r = 3; r < RK + 4; ++r) planeq[r] = planeq[r - 1] + ((k0 - 2 + r <= g.np - 1) ? g.plane : 0L);
     // distance of block-local coordinate a in [-2, R+1] from the output range [0, R-1]
 #define SF_DIST(a_, R_) ((a_) < 0 ? -(a_) : ((a_) > (R_)-1 ? (a_) - ((R_)-1) : 0))
 
