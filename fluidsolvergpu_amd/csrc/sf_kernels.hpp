@@ -874,10 +874,15 @@ __global__ void __launch_bounds__(256, SF_J2_WAVES) jacobi2_kernel(Geom g, Jacob
                 yp = has_right ? dn : sh_first[wave < 3 ? wave + 1 : 3][rk * RJ + rj];
             if (!active || kl >= ke || j > N) continue;
             V jm = Y[rk + 1][rj], jp = Y[rk + 1][rj + 2], km = Y[rk][rj + 1], kp = Y[rk + 2][rj + 1];
-            if (j == 1) jm = sy * yc;
-            if (j == N) jp = sy * yc;
-            if (g.wall_lo && kg == 1) km = sz * yc;
-            if (g.wall_hi && kg == N) kp = sz * yc;
+            // first-sweep set_bnd on the j / k walls. Most waves touch no wall: one wave-uniform test lets them skip
+            // the per-element selects (about a seventh of the kernel's vector instructions)
+            const bool near_wall = (j == 1) | (j == N) | (g.wall_lo && kg == 1) | (g.wall_hi && kg == N);
+            if (__builtin_amdgcn_ballot_w64(near_wall) != 0ull) {
+                if (j == 1) jm = sy * yc;
+                if (j == N) jp = sy * yc;
+                if (g.wall_lo && kg == 1) km = sz * yc;
+                if (g.wall_hi && kg == N) kp = sz * yc;
+            }
             const V s = S[rk + 1][rj + 1];
             T out[W];
 #pragma unroll
