@@ -237,7 +237,8 @@ def main():
             "config": {"workload": f"{N}^3 {args.dtype}, K={K} Jacobi iters per lin_solve, vel_step+dens_step "
                                    f"with per-step source re-injection", "grid": N, "jacobi_iters": K,
                        "slabs": world * args.local_slabs, "cells_per_gpu": cells / world,
-                       "parallelism": f"k-slab x{world}" + (" (RCCL halo exchange)" if world > 1 else "")},
+                       "parallelism": f"k-slab x{world}" + (" (RCCL halo exchange)" if world > 1 else ""),
+                       "schedule": fs.schedule_info() if hasattr(fs, "schedule_info") else None},
             "achieved_hbm_gbps_step": step_bytes / (elapsed / args.steps) / 1e9 / world,
             "step_algorithmic_bytes_per_cell": words_per_cell_step(K) * wsize,
             "hbm_copy_gbps_same_run": copy_gbps,

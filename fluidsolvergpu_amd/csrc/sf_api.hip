@@ -16,6 +16,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <chrono>
 #include <climits>
 #include <cstdio>
 #include <cstdlib>
@@ -93,6 +94,7 @@ public:
     virtual float timer_stop() = 0;
     virtual double copy_bandwidth(size_t bytes, int reps) = 0;
     virtual void layout_info(int* pitch, int* planes, size_t* bytes) const = 0;
+    virtual void schedule_info(int* trap, int* measured) const = 0;
     virtual int lin_solve_launches(int iters) const = 0;
     virtual void snapshot(const int* fields, int nfields) = 0;
     virtual void snapshot_read(int index, void* host) = 0;
@@ -234,10 +236,53 @@ public:
         ovl_mode_ = env_int("SF_OVL", 1);
         split_fields_ = env_int("SF_SPLIT_FIELDS", 1);
         fuse_src_ = env_int("SF_FUSE_SRC", 1) != 0;  // fold add_source (bound sources) into diffuse's first sweep pair  // 0 never, 1 when one field fits the Infinity Cache, 2 always
-        trap_m_ = env_int("SF_TRAP", 5);  // pairs per trapezoid block of a decomposed lin_solve (<= 1: off)
+        // Trapezoid blocks shorten the interior chain (no cross-stream wait) but lengthen the boundary chain
+        // B(j) -> halo(j) -> B(j+1), because B grows by two planes per side and pair. With halos that are copies on
+        // this GPU the interior chain is the critical one (default 5 pairs per block); with RCCL messages over xGMI
+        // (2.4 MB per direction and pair at 512^2: tens of microseconds) the boundary chain is, so the default there
+        // keeps B at its minimum size (0 = off) unless the measurement at the end of this constructor
+        // (tune_schedule) says otherwise. SF_TRAP overrides and switches the measurement off.
+        trap_m_ = env_int("SF_TRAP", nranks_ > 1 ? 0 : 5);  // pairs per trapezoid block of a decomposed lin_solve (<= 1: off)
         strip_mode_ = env_int("SF_STRIP", 0);  // 0 heuristic, 1 dense, 2 wave-aligned row strips in the fused kernel
         graphs_ = env_int("SF_GRAPH", 0) != 0 && P_ == 1;
         SF_HIP(hipDeviceSynchronize());
+        if (nranks_ > 1 && std::getenv("SF_TRAP") == nullptr && env_int("SF_AUTOTUNE", 1)) tune_schedule();
+    }
+
+    // Which trapezoid depth suits THIS machine's halo latency (see the comment at trap_m_)? Times a 20-sweep
+    // lin_solve on the (still zero) density slots for 0, 2 and 5 pairs per block and keeps the fastest, preferring
+    // the shallower one unless the deeper is 3 % faster. Every rank runs the same sequence of exchanges whatever it
+    // picks (the depth only moves planes between this rank's own two launches), so ranks may differ in their choice.
+    void tune_schedule() {
+        if (!(G_ == 2 && can_fuse2()) || nzl_ <= 2 * (G_ + 2) + 2) return;
+        const int x[1] = {SF_DENS}, x0[1] = {SF_DENS0}, b0[1] = {0};
+        const T a = T(0.25), c = T(1) + T(6) * a;
+        auto drain = [&] {
+            join();
+            for (Slab& sl : slabs_) {
+                SF_HIP(hipStreamSynchronize(sl.cs));
+                SF_HIP(hipStreamSynchronize(sl.bs));
+                SF_HIP(hipStreamSynchronize(sl.hs));
+            }
+        };
+        const int cand[3] = {0, 2, 5};
+        double best = 0;
+        int best_m = 0;
+        for (int q = 0; q < 3; ++q) {
+            trap_m_ = cand[q];
+            op_lin_solve<1>(x, x0, b0, a, c, 10);  // warm-up (first use of the communicator, caches)
+            drain();
+            const auto t0 = std::chrono::steady_clock::now();
+            for (int r = 0; r < 3; ++r) op_lin_solve<1>(x, x0, b0, a, c, 20);
+            drain();
+            const double t = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (q == 0 || t < 0.97 * best) {
+                best = t;
+                best_m = cand[q];
+            }
+        }
+        trap_m_ = best_m;
+        tuned_trap_ = best_m;
     }
 
     ~Solver() override {
@@ -755,6 +800,10 @@ public:
 
     int lin_solve_launches(int iters) const override { return can_fuse2() ? iters / 2 + iters % 2 : iters; }
 
+    void schedule_info(int* trap, int* measured) const override {
+        if (trap) *trap = trap_m_ > 1 ? trap_m_ : 0;
+        if (measured) *measured = tuned_trap_ >= 0 ? 1 : 0;
+    }
     void layout_info(int* pitch, int* planes, size_t* bytes) const override {
         if (pitch) *pitch = px_;
         if (planes) *planes = nplanes_;
@@ -1478,7 +1527,7 @@ private:
     int N_, K_, device_;
     int L_ = 1, nranks_ = 1, rank_ = 0, P_ = 1, G_ = 1;
     int fuse_maxvec_ = 128, strip_mode_ = 0, ovl_mode_ = 1;
-    int trap_m_ = 4, trap_extra_ = 0, split_fields_ = 1;
+    int trap_m_ = 4, trap_extra_ = 0, split_fields_ = 1, tuned_trap_ = -1;
     int bound_[4] = {-1, -1, -1, -1};  // resident source slots (sf_bind_sources)
     bool pending_join_ = false, split_enabled_ = true, graphs_ = false;
     std::vector<GraphEntry> graph_cache_;
@@ -1694,6 +1743,11 @@ int sf_lin_solve_launches(const sf_ctx* ctx, int iters) {
 int sf_layout_info(const sf_ctx* ctx, int* row_pitch, int* planes_per_slab, size_t* bytes_per_field) {
     if (!ctx || !ctx->impl) return SF_ERR_INVALID;
     ctx->impl->layout_info(row_pitch, planes_per_slab, bytes_per_field);
+    return SF_OK;
+}
+int sf_schedule_info(const sf_ctx* ctx, int* trapezoid_pairs, int* measured) {
+    if (!ctx || !ctx->impl) return SF_ERR_INVALID;
+    ctx->impl->schedule_info(trapezoid_pairs, measured);
     return SF_OK;
 }
 

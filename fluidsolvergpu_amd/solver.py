@@ -29,7 +29,7 @@ ABI_SYMBOLS = (
     "sf_download", "sf_download_planes", "sf_upload_planes", "sf_owned_planes", "sf_stored_planes", "sf_fill", "sf_copy_field", "vel_step",
     "dens_step", "sf_add_source", "sf_set_bnd", "sf_lin_solve", "sf_diffuse", "sf_advect", "sf_project",
     "sf_set_iters", "sf_set_coefficients", "sf_sync", "sf_last_error", "sf_timer_start", "sf_timer_stop",
-    "sf_measure_copy_bandwidth", "sf_layout_info", "sf_lin_solve_launches", "sf_snapshot", "sf_snapshot_read",
+    "sf_measure_copy_bandwidth", "sf_layout_info", "sf_schedule_info", "sf_lin_solve_launches", "sf_snapshot", "sf_snapshot_read",
     "sf_tracers_set", "sf_tracers_advect", "sf_tracers_get", "sf_bind_sources",
 )
 
@@ -80,6 +80,7 @@ lib.sf_tracers_set.argtypes = [_ctx, C.c_int, C.c_void_p]
 lib.sf_tracers_advect.argtypes = [_ctx]
 lib.sf_tracers_get.argtypes = [_ctx, C.c_void_p, C.c_void_p, C.c_void_p]
 lib.sf_layout_info.argtypes = [_ctx, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_size_t)]
+lib.sf_schedule_info.argtypes = [_ctx, C.POINTER(C.c_int), C.POINTER(C.c_int)]
 
 
 class SfError(RuntimeError):
@@ -275,6 +276,11 @@ class FluidSolver:
 
     def lin_solve_launches(self, iters):
         return int(lib.sf_lin_solve_launches(self._h, int(iters)))
+
+    def schedule_info(self):
+        trap, measured = C.c_int(), C.c_int()
+        self._ck(lib.sf_schedule_info(self._h, C.byref(trap), C.byref(measured)))
+        return {"trapezoid_pairs": trap.value, "measured": bool(measured.value)}
 
     def layout_info(self):
         pitch, planes, nbytes = C.c_int(), C.c_int(), C.c_size_t()

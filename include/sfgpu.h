@@ -171,6 +171,10 @@ int sf_lin_solve_launches(const sf_ctx* ctx, int iters);
  * bytes per field per slab. Any pointer may be NULL. */
 int sf_layout_info(const sf_ctx* ctx, int* row_pitch, int* planes_per_slab, size_t* bytes_per_field);
 
+/* Launch schedule of a decomposed lin_solve, for reports: pairs per trapezoid block (0 = boundary launch of fixed
+ * size) and whether sf_create measured it on this machine (1) or took the default / SF_TRAP (0). */
+int sf_schedule_info(const sf_ctx* ctx, int* trapezoid_pairs, int* measured);
+
 #ifdef __cplusplus
 }
 #endif

@@ -352,6 +352,13 @@ def test_loopback_rank_share_context():
         fs.sync()
         d = fs.download_planes("dens", 9, 17)
         assert np.isfinite(d).all()
+        assert fs.schedule_info()["measured"] is False  # slab too thin for a trapezoid block: nothing to measure
+    # a slab thick enough: sf_create times the candidate schedules and leaves the fields zero
+    with S().FluidSolver(96, dtype="f32", iters=4, rank=0, nranks=2, flags=1) as fs:
+        info = fs.schedule_info()
+        assert info["measured"] is True and info["trapezoid_pairs"] in (0, 2, 5)
+        kb, ke = fs.owned_planes()
+        assert not fs.download_planes("dens", kb, ke).any() and not fs.download_planes("dens0", kb, ke).any()
 
 
 def test_upload_planes_fills_all_ghosts():

@@ -57,7 +57,8 @@ def main():
     cells_rank = float(N) ** 3 / R
     print(json.dumps({"emulation": "rank-share (loopback halo)", "ranks": R, "rank": r, "grid": N, "ms_per_step": ms,
                       "mcells_per_s_per_rank": cells_rank / ms / 1e3,
-                      "implied_aggregate_mcells_per_s": cells_rank * R / ms / 1e3}), flush=True)
+                      "implied_aggregate_mcells_per_s": cells_rank * R / ms / 1e3,
+                      "schedule": fs.schedule_info()}), flush=True)
     fs.close()
 
 
