@@ -159,10 +159,10 @@ public:
         px_ = ceil_div(lead_ + N_ + 1 + W, line) * line;
         plane_ = (long)px_ * (N_ + 2);
         // two ghost planes per side let sweep pairs be fused across slab boundaries (one exchange per pair); grids
-        // the fused kernel does not take (rows wider than 128 vectors, N not a multiple of W) keep one ghost plane
+        // the fused kernel does not take (rows wider than SF_FUSE_MAXVEC vectors, N not a multiple of W) keep one ghost plane
         // and exchange one plane per sweep
         const bool fusable = env_int("SF_FUSE2", 1) != 0 && env_int("SF_JACOBI", 2) != 0 && N_ % W == 0 &&
-                             N_ / W <= env_int("SF_FUSE_MAXVEC", 128);
+                             N_ / W <= env_int("SF_FUSE_MAXVEC", 512);
         G_ = (P_ > 1 && nzl_ >= 2 && fusable && env_int("SF_GHOST", 2) >= 2) ? 2 : 1;
         nplanes_ = nzl_ + 2 * G_;
         field_elems_ = plane_ * nplanes_ + 256;  // slack so whole-vector accesses never leave the buffer
@@ -230,7 +230,7 @@ public:
         kc2_ = env_int("SF_KC2", 32);
         advect_lds_ = env_int("SF_ADVECT_LDS", 0) != 0;
         zero_skip_ = env_int("SF_ZERO_SKIP", 1) != 0;
-        fuse_maxvec_ = env_int("SF_FUSE_MAXVEC", 128);
+        fuse_maxvec_ = env_int("SF_FUSE_MAXVEC", 512);
         tx_override_ = env_int("SF_TX", 0);
         split_enabled_ = env_int("SF_SPLIT", 1) != 0;
         ovl_mode_ = env_int("SF_OVL", 1);
@@ -1174,7 +1174,7 @@ private:
 
     // Two fused sweeps (temporal blocking). Usable when a row fits one workgroup, N is a multiple of the
     // vector width and the grid is not decomposed (a second ghost plane would be needed).
-    // (measured: +5 % at 512^3, +12 % at 256^3, -8 % at 1024^3 where a row spans four waves -> rows <= 128 vectors)
+    // (measured against single sweeps: +20 % at 512^3, +35 % at 256^3, +11 % at 1024^3 fp32, +15 % at 512^3 fp64)
     bool can_fuse2() const {
         return fuse2_ && (P_ == 1 || G_ == 2) && N_ % W == 0 && N_ / W <= fuse_maxvec_ && jacobi_mode_ != 0;
     }
@@ -1215,7 +1215,11 @@ private:
         m.gap = gap_;
         // rows that neither fill whole waves nor divide one: the seam-free overlapped mapping (SF_OVL: 0 never,
         // 1 for such rows (default), 2 for every width)
-        const bool ovl = ovl_mode_ == 2 || (ovl_mode_ == 1 && nvec % 64 != 0 && 64 % nvec != 0);
+        // ... and rows wider than two waves, where it also beats one row strip per workgroup (1024^3 fp32: 2026 vs
+        // 1986 us/sweep; the single-sweep kernel: 2207)
+        // (a row strip must fit the 256 threads of a workgroup: beyond that only the overlapped mapping exists)
+        const bool ovl = ovl_mode_ == 2 || (ovl_mode_ == 1 && ((nvec % 64 != 0 && 64 % nvec != 0) || nvec > 128)) ||
+                         nvec > 256;
         if (ovl) {
             const int items = ceil_div(N_, RJ) * nvec;
             m.gy = ceil_div(ceil_div(items, sfk::SF_OVL_OUT), 4);
@@ -1526,7 +1530,7 @@ private:
 
     int N_, K_, device_;
     int L_ = 1, nranks_ = 1, rank_ = 0, P_ = 1, G_ = 1;
-    int fuse_maxvec_ = 128, strip_mode_ = 0, ovl_mode_ = 1;
+    int fuse_maxvec_ = 512, strip_mode_ = 0, ovl_mode_ = 1;
     int trap_m_ = 4, trap_extra_ = 0, split_fields_ = 1, tuned_trap_ = -1;
     int bound_[4] = {-1, -1, -1, -1};  // resident source slots (sf_bind_sources)
     bool pending_join_ = false, split_enabled_ = true, graphs_ = false;

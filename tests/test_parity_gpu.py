@@ -101,12 +101,11 @@ def test_lin_solve(N, K, b, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "f64"])
-@pytest.mark.parametrize("N,K,b", [(100, 4, 1), (108, 5, 2), (20, 6, 3), (324, 4, 0), (408, 2, 1)])
+@pytest.mark.parametrize("N,K,b", [(100, 4, 1), (108, 5, 2), (20, 6, 3), (324, 4, 0), (408, 2, 1), (516, 2, 3)])
 def test_lin_solve_rows_that_straddle_waves(N, K, b, dtype):
-    """Row widths that are not a power of two: the fused kernel packs several row strips into one 256-thread
-    workgroup, so wave seams fall inside rows (LDS hand-over) and rows start in the middle of a wave."""
-    if dtype == np.float64 and N > 200:
-        pytest.skip("rows wider than 128 vectors use the single-sweep kernel; covered elsewhere")
+    """Row widths that are not a power of two, and rows wider than two waves (up to 258 vectors here): the fused
+    kernel's overlapped mapping packs the (row pair, vector) items of a plane pair into 60-lane windows, so rows
+    start and end anywhere inside a wave."""
     f = rand_fields(N, dtype, 50)
     a, c = 0.21, 1 + 6 * 0.21
     with make(N, dtype) as fs:
