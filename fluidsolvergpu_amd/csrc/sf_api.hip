@@ -196,9 +196,19 @@ public:
                 // SF_HALO_PRIO=1 gives the halo stream the highest priority so its traffic does not queue behind the
                 // interior sweep. Off by default: with logical slabs on ONE GPU it doubles the step time (the copy
                 // kernel pre-empts the sweeps); whether it pays with RCCL across GPUs is still to be measured.
+                // One slab per process (production): every halo is an RCCL message, and the chain
+                // boundary launch -> message -> next boundary launch is what limits a pair once the messages take as
+                // long as the interior work. Issued on ONE stream that chain needs no cross-stream hand-over (each
+                // costs ~10 us, tools/evgap.hip): the halo "stream" is then the boundary stream itself
+                // (SF_HALO_STREAM=1 keeps a separate one). With several slabs per process the copies pull from the
+                // neighbours' buffers and stay on their own stream (SF_HALO_STREAM=2 shares there too: used by the
+                // parity tests to run the shared-stream ordering against the oracle).
                 int lo = 0, hi = 0;
                 SF_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-                if (env_int("SF_HALO_PRIO", 0))
+                const int hmode = env_int("SF_HALO_STREAM", 0);  // 0 as described, 1 always separate, 2 always shared
+                if (((L_ == 1 && nranks_ > 1 && hmode == 0) || hmode == 2) && !env_int("SF_HALO_PRIO", 0))
+                    sl.hs = sl.bs;
+                else if (env_int("SF_HALO_PRIO", 0))
                     SF_HIP(hipStreamCreateWithPriority(&sl.hs, hipStreamNonBlocking, hi));
                 else
                     SF_HIP(hipStreamCreateWithFlags(&sl.hs, hipStreamNonBlocking));
@@ -303,7 +313,7 @@ public:
             if (sl.cs) (void)hipStreamDestroy(sl.cs);
             if (sl.bs) (void)hipStreamDestroy(sl.bs);
             if (sl.cs_mark) (void)hipEventDestroy(sl.cs_mark);
-            if (sl.hs) (void)hipStreamDestroy(sl.hs);
+            if (sl.hs && sl.hs != sl.bs) (void)hipStreamDestroy(sl.hs);
             if (sl.boundary_done) (void)hipEventDestroy(sl.boundary_done);
             if (sl.halo_done) (void)hipEventDestroy(sl.halo_done);
         }

@@ -317,6 +317,37 @@ def test_slabs_trapezoid_schedule(N, P, K, trap, monkeypatch):
             assert_same(got[n], want[n], f"N={N} P={P} K={K} trap={trap} rep={rep}: {n}")
 
 
+@pytest.mark.parametrize("N,P,K", [(128, 2, 8), (96, 4, 5), (64, 8, 4), (160, 2, 20)])
+def test_slabs_halo_on_the_boundary_stream(N, P, K, monkeypatch):
+    """One slab per process issues its halo messages on the boundary stream (no cross-stream hand-over in the chain
+    boundary launch -> message -> next boundary launch). SF_HALO_STREAM=2 applies the same stream sharing to the
+    logical slabs of one process, where the result can be checked: bit-identical to the single-slab run, with bound
+    sources (folded add_source + ghost-plane right-hand side on that stream) and without."""
+    dtype = np.float32
+    monkeypatch.setenv("SF_HALO_STREAM", "2")
+    f = small_velocity(rand_fields(N, dtype, 80 + P), N, dtype)
+
+    def run(nslabs, bound):
+        with make(N, dtype, K=K, nslabs_local=nslabs) as fs:
+            for n in NAMES:
+                fs.upload(n, f[n])
+            if bound:
+                for slot, n in (("user0", "u0"), ("user1", "v0"), ("user2", "w0"), ("user3", "dens0")):
+                    fs.upload(slot, f[n])
+                fs.bind_sources("user0", "user1", "user2", "user3")
+            for _ in range(2):
+                fs.vel_step()
+                fs.dens_step()
+            fs.sync()
+            return {n: fs.download(n) for n in ("u", "v", "w", "dens")}
+
+    for bound in (False, True):
+        want = run(1, bound)
+        got = run(P, bound)
+        for n in want:
+            assert_same(got[n], want[n], f"N={N} P={P} K={K} bound={bound}: {n}")
+
+
 @pytest.mark.parametrize("split", ["0", "2"])
 def test_diffuse_fields_together_or_one_by_one(split, monkeypatch):
     """SF_SPLIT_FIELDS: u, v, w diffused in one three-field launch per pair or one field after the other."""
