@@ -584,13 +584,17 @@ __global__ void __launch_bounds__(256) jacobi_rb_kernel(Geom g, JacobiArgs<T, NF
 // x'' = J(J(x)) computed in one kernel: each thread produces RJ x RK output vectors and recomputes, in
 // registers, the first-sweep values y = J(x) on the cross-shaped neighbourhood its outputs need
 // (dist <= 1 around the RJ x RK block; x itself is read at dist <= 2). Redundant first-sweep work is
-// (RJ+2)(RK+2)-4 over RJ*RK vectors (3x at 2x2) — VALU is idle in this bandwidth-bound kernel — while
-// HBM traffic per sweep halves: x, x0 are read once and x'' is written once for two sweeps.
+// (RJ+2)(RK+2)-4 over RJ*RK vectors (3x at 2x2) while HBM traffic per sweep halves: x, x0 are read once and x''
+// is written once for two sweeps. (With the traffic halved the kernel is bound by instruction issue and latency at
+// its two waves per SIMD — about 760 vector + 280 scalar instructions per wave and 1,024 cells — so instruction
+// count matters: see the notes at the load phase, the grid decode and the wall selects.)
 // The first sweep's set_bnd is applied in registers (y on a wall row/plane is +-y of the adjacent
 // interior row/plane; its i-shell is sx*y[1], sx*y[N]), so the result is bit-identical to two separate
-// sweeps. A workgroup spans whole rows (blockDim.x = ceil(N/W) rounded up to 64); the only values that
-// cross waves are the end cells of y, exchanged through a few words of LDS.
-// Requirements (checked by the launcher): N % W == 0, ceil(N/W) <= 256, one slab (P = 1).
+// sweeps. In the strip mappings a 256-thread workgroup holds whole row strips; the only values that cross waves
+// are the end cells of y (and of x, see XLDS), exchanged through a few words of LDS. The overlapped mapping (OVL)
+// has no cross-wave values at all.
+// Requirements (checked by the launcher): N % W == 0; strips: a row fits one workgroup (N/W <= 256); decomposed
+// grids need two ghost planes per side (G = 2).
 #ifndef SF_J2_WAVES
 #define SF_J2_WAVES 2
 #endif
