@@ -857,6 +857,13 @@ __global__ void __launch_bounds__(256, SF_J2_WAVES) jacobi2_kernel(Geom g, Jacob
     }
 
     // ---- second sweep --------------------------------------------------------------------------------
+    // Most waves touch no wall: two wave-uniform tests (supersets of the per-output conditions) let them skip the
+    // per-element wall selects and the shell stores altogether — about a sixth of the kernel's instructions
+    const bool near_jk = (j0 <= 1) | (j0 + RJ - 1 >= N) | (g.wall_lo && g.kg0 + k0 <= 1) |
+                         (g.wall_hi && g.kg0 + k0 + RK - 1 >= N);
+    const bool wave_walls = __builtin_amdgcn_ballot_w64(near_jk) != 0ull;
+    const bool wave_shells =
+        wave_walls || (m.ishell_write != 0 && __builtin_amdgcn_ballot_w64(first_vec | last_vec) != 0ull);
 #pragma unroll
     for (int rk = 0; rk < RK; ++rk) {
         const int kl = k0 + rk;
@@ -878,10 +885,7 @@ __global__ void __launch_bounds__(256, SF_J2_WAVES) jacobi2_kernel(Geom g, Jacob
                 yp = has_right ? dn : sh_first[wave < 3 ? wave + 1 : 3][rk * RJ + rj];
             if (!active || kl >= ke || j > N) continue;
             V jm = Y[rk + 1][rj], jp = Y[rk + 1][rj + 2], km = Y[rk][rj + 1], kp = Y[rk + 2][rj + 1];
-            // first-sweep set_bnd on the j / k walls. Most waves touch no wall: one wave-uniform test lets them skip
-            // the per-element selects (about a seventh of the kernel's vector instructions)
-            const bool near_wall = (j == 1) | (j == N) | (g.wall_lo && kg == 1) | (g.wall_hi && kg == N);
-            if (__builtin_amdgcn_ballot_w64(near_wall) != 0ull) {
+            if (wave_walls) {  // first-sweep set_bnd on the j / k walls
                 if (j == 1) jm = sy * yc;
                 if (j == N) jp = sy * yc;
                 if (g.wall_lo && kg == 1) km = sz * yc;
@@ -904,7 +908,7 @@ __global__ void __launch_bounds__(256, SF_J2_WAVES) jacobi2_kernel(Geom g, Jacob
             else
                 stv(xn + q, o);
             if (SRC) stv(x0out + q, s);
-            emit_shells<T, W>(xn, g, b, i0, j, kl, out, W, m.ishell_write != 0);
+            if (wave_shells) emit_shells<T, W>(xn, g, b, i0, j, kl, out, W, m.ishell_write != 0);
         }
     }
 #undef SF_DIST
