@@ -293,6 +293,41 @@ public:
         }
         trap_m_ = best_m;
         tuned_trap_ = best_m;
+        // Same question for "u, v, w one field at a time" (Infinity-Cache resident, three small messages per pair)
+        // against "three fields per launch" (one message of three times the size: the message latency is paid once):
+        // the first wins when a pair is compute-bound, the second when the messages are the critical chain.
+        const double one = 3.0 * (double)(N_ + 2) * (N_ + 2) * nplanes_ * sizeof(T);
+        if (std::getenv("SF_SPLIT_FIELDS") == nullptr && one <= 0.9 * 256.0 * 1048576.0) {
+            const int vel[3] = {SF_U, SF_V, SF_W}, vel0[3] = {SF_U0, SF_V0, SF_W0}, b123[3] = {1, 2, 3};
+            double t_split = 0;
+            for (int q = 0; q < 2; ++q) {
+                split_fields_ = q == 0 ? 1 : 0;
+                op_lin_solve<3>(vel, vel0, b123, a, c, 4);
+                drain();
+                const auto t0 = std::chrono::steady_clock::now();
+                for (int r = 0; r < 2; ++r) op_lin_solve<3>(vel, vel0, b123, a, c, 20);
+                drain();
+                const double t = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                if (q == 0)
+                    t_split = t;
+                else if (!(t < 0.97 * t_split))
+                    split_fields_ = 1;
+            }
+            // unlike the trapezoid depth this changes the sequence of exchanges, so the ranks must agree: the batched
+            // form is used only if every rank prefers it
+            if (comm_) {
+                int* d_vote = nullptr;
+                int vote = split_fields_ == 0 ? 1 : 0, sum = 0;
+                SF_HIP(hipMalloc(&d_vote, sizeof(int)));
+                SF_HIP(hipMemcpy(d_vote, &vote, sizeof(int), hipMemcpyHostToDevice));
+                SF_NCCL(ncclAllReduce(d_vote, d_vote, 1, ncclInt, ncclSum, comm_, slabs_[0].cs));
+                SF_HIP(hipStreamSynchronize(slabs_[0].cs));
+                SF_HIP(hipMemcpy(&sum, d_vote, sizeof(int), hipMemcpyDeviceToHost));
+                SF_HIP(hipFree(d_vote));
+                split_fields_ = (sum == nranks_) ? 0 : 1;
+            }
+            tuned_split_ = split_fields_;
+        }
     }
 
     ~Solver() override {
@@ -812,7 +847,7 @@ public:
 
     void schedule_info(int* trap, int* measured) const override {
         if (trap) *trap = trap_m_ > 1 ? trap_m_ : 0;
-        if (measured) *measured = tuned_trap_ >= 0 ? 1 : 0;
+        if (measured) *measured = (tuned_trap_ >= 0 ? 1 : 0) | (tuned_split_ >= 0 ? 2 : 0) | (split_fields_ == 0 ? 4 : 0);
     }
     void layout_info(int* pitch, int* planes, size_t* bytes) const override {
         if (pitch) *pitch = px_;
@@ -1541,7 +1576,7 @@ private:
     int N_, K_, device_;
     int L_ = 1, nranks_ = 1, rank_ = 0, P_ = 1, G_ = 1;
     int fuse_maxvec_ = 512, strip_mode_ = 0, ovl_mode_ = 1;
-    int trap_m_ = 4, trap_extra_ = 0, split_fields_ = 1, tuned_trap_ = -1;
+    int trap_m_ = 4, trap_extra_ = 0, split_fields_ = 1, tuned_trap_ = -1, tuned_split_ = -1;
     int bound_[4] = {-1, -1, -1, -1};  // resident source slots (sf_bind_sources)
     bool pending_join_ = false, split_enabled_ = true, graphs_ = false;
     std::vector<GraphEntry> graph_cache_;

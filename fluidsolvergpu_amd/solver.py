@@ -280,7 +280,9 @@ class FluidSolver:
     def schedule_info(self):
         trap, measured = C.c_int(), C.c_int()
         self._ck(lib.sf_schedule_info(self._h, C.byref(trap), C.byref(measured)))
-        return {"trapezoid_pairs": trap.value, "measured": bool(measured.value)}
+        m = measured.value
+        return {"trapezoid_pairs": trap.value, "measured": bool(m & 1), "fields_measured": bool(m & 2),
+                "fields_per_launch": 3 if (m & 4) else 1}
 
     def layout_info(self):
         pitch, planes, nbytes = C.c_int(), C.c_int(), C.c_size_t()

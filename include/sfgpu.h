@@ -172,7 +172,8 @@ int sf_lin_solve_launches(const sf_ctx* ctx, int iters);
 int sf_layout_info(const sf_ctx* ctx, int* row_pitch, int* planes_per_slab, size_t* bytes_per_field);
 
 /* Launch schedule of a decomposed lin_solve, for reports: pairs per trapezoid block (0 = boundary launch of fixed
- * size) and whether sf_create measured it on this machine (1) or took the default / SF_TRAP (0). */
+ * size); `measured` bit 0: sf_create measured the depth on this machine (else default / SF_TRAP), bit 1: it also
+ * measured "u,v,w one field at a time" against "three fields per launch", bit 2: the three-field form is in use. */
 int sf_schedule_info(const sf_ctx* ctx, int* trapezoid_pairs, int* measured);
 
 #ifdef __cplusplus

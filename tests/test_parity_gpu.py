@@ -388,7 +388,9 @@ def test_loopback_rank_share_context():
         info = fs.schedule_info()
         assert info["measured"] is True and info["trapezoid_pairs"] in (0, 2, 5)
         kb, ke = fs.owned_planes()
-        assert not fs.download_planes("dens", kb, ke).any() and not fs.download_planes("dens0", kb, ke).any()
+        assert info["fields_measured"] is True and info["fields_per_launch"] in (1, 3)
+        for n in ("dens", "dens0", "u", "v0", "w"):
+            assert not fs.download_planes(n, kb, ke).any(), f"{n} must still be zero after the schedule measurement"
 
 
 def test_upload_planes_fills_all_ghosts():
