@@ -370,6 +370,10 @@ struct TileMap {
                 // 64 keeps every strip aligned to wave boundaries at the price of idle lanes)
     int strip_shift;       // log2(strip) when strip is a power of two, else -1 (spares the kernel a division)
     unsigned nvec_magic;   // floor(2^32 / (N/W)) + 1: t / (N/W) == umulhi(t, magic) for the t < 2^16 of the OVL mapping
+    // jacobi2_kernel: every thread touches one 128-byte line of the tile pf_dz plane blocks ahead at the same (j, i)
+    // position — the lines only that tile brings in: its own rows of x and x0 — so that the workgroup which gets
+    // there ~32 workgroups later finds them in L2 / Infinity Cache instead of HBM. 0 = off.
+    int pf_dz;
 };
 
 __device__ __forceinline__ int plane_of(const TileMap& m, int kb, int t) {
@@ -649,6 +653,7 @@ __global__ void __launch_bounds__(256, SF_J2_WAVES) jacobi2_kernel(Geom g, Jacob
     const int N = g.N;
     const int nvec = N / W;
     const int k0 = plane_of(m, kb, kk * RK);
+    const int nlogical = ke - kb;  // logical planes of this launch
     {
         const int left = (ke - kb) - kk * RK;
         ke = k0 + (left < RK ? left : RK);  // physical end of this block's planes
@@ -778,6 +783,17 @@ __global__ void __launch_bounds__(256, SF_J2_WAVES) jacobi2_kernel(Geom g, Jacob
                     }
                 }
             }
+    }
+    // L2 / Infinity-Cache warm-up for the workgroup that will run pf_dz plane blocks further on (see TileMap). The
+    // eight threads whose vectors share a 128-byte line take one (array, plane, row) combination each, so every
+    // line of that tile's own rows is requested once; requested last so that no wait for the vectors above includes
+    // it; the value is never used.
+    static_assert(RJ == 2 && RK == 2, "warm-up line assignment assumes a 2x2 block");
+    int pf = 0;  // one dword is enough to bring the line in, whatever T is
+    if (!XZ && m.pf_dz > 0 && (kk + m.pf_dz) * RK + RK <= nlogical) {
+        const int c = vec & 7;
+        const int kpf = plane_of(m, kb, (kk + m.pf_dz) * RK + ((c >> 1) & 1));
+        pf = *reinterpret_cast<const int*>(((c & 1) ? x0 : x) + (long)kpf * g.plane + rowq[2 + (c >> 2)]);
     }
     // nothing below may be scheduled above this point and no load below it: all requests are out before any use
     __builtin_amdgcn_sched_barrier(0);
@@ -911,6 +927,7 @@ __global__ void __launch_bounds__(256, SF_J2_WAVES) jacobi2_kernel(Geom g, Jacob
             if (wave_shells) emit_shells<T, W>(xn, g, b, i0, j, kl, out, W, m.ishell_write != 0);
         }
     }
+    if (!XZ) asm volatile("" ::"v"(pf));  // keeps the warm-up load; it completed long ago (loads return in order)
 #undef SF_DIST
 }
 
