@@ -1275,14 +1275,14 @@ private:
         // 512^3), expressed in plane blocks at the same j position
         // Automatic mode: only where the data comes from HBM (x, x0, x' of the launch's fields exceed the Infinity
         // Cache: a resident working set gains nothing, 256^3) and only where a plane block is a fine enough unit of
-        // distance (<= 48 workgroups per XCD and plane block; with more — rows of 256 vectors — "one block ahead" is
-        // ~2 MB per XCD, which evicts the j / k reuse from the 4 MB L2: 1024^3 ran 8 % slower).
+        // distance (<= 48 workgroups per XCD and plane block) and rows are at most 128 vectors wide: with rows of 256
+        // vectors the early lines evict the j / k reuse from the 4 MB L2 (1024^3 fp32 ran 8 % slower, 512^3 fp64 5-15 %).
         {
             const int per_xcd_round = m.band > 0 ? m.band : m.gy;
             const double ws = 3.0 * NF * (double)(N_ + 2) * (N_ + 2) * nplanes_ * sizeof(T);
             if (prefetch_ > 0)
                 m.pf_dz = prefetch_;
-            else if (prefetch_ < 0 && per_xcd_round <= 48 && ws > 0.9 * 256.0 * 1048576.0)
+            else if (prefetch_ < 0 && per_xcd_round <= 48 && nvec <= 128 && ws > 0.9 * 256.0 * 1048576.0)
                 m.pf_dz = std::max(1, (32 + per_xcd_round / 2) / std::max(1, per_xcd_round));
             else
                 m.pf_dz = 0;
