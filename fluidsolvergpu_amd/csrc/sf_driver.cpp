@@ -28,6 +28,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <filesystem>
 #include <iostream>
 #include <sstream>
 #include <string>
@@ -124,6 +125,11 @@ static Options parse(int argc, char** argv) {
             fprintf(stderr, "unknown option %s\n", s.c_str());
             exit(2);
         }
+    }
+    // frames go to <out>/: create it (the reference writes into the working directory, which always exists)
+    if (o.every > 0) {
+        std::error_code ec;
+        std::filesystem::create_directories(o.out, ec);
     }
     return o;
 }
