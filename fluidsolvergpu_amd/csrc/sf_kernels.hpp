@@ -737,6 +737,7 @@ __global__ void __launch_bounds__(256, SF_J2_WAVES) jacobi2_kernel(Geom g, Jacob
     // its divergent branch).
     const bool left_mem = !XZ && (first_vec ? m.ishell_mem != 0 : (!has_left && !XLDS));
     const bool right_mem = !XZ && (last_vec ? m.ishell_mem != 0 : (!has_right && !XLDS));
+    const bool mirror_l = first_vec && m.ishell_mem == 0, mirror_r = last_vec && m.ishell_mem == 0;
     T XL[NYPOS], XR[NYPOS];
 #pragma unroll
     for (int pos = 0; pos < NYPOS; ++pos) XL[pos] = XR[pos] = T(0);
@@ -833,19 +834,20 @@ __global__ void __launch_bounds__(256, SF_J2_WAVES) jacobi2_kernel(Geom g, Jacob
             const T up = lane_up(cc[W - 1]);
             const T dn = lane_dn(cc[0]);
             const int pos = (c + 1) * (RJ + 2) + (r + 1);
-            T xm, xp;
+            // straight selects on loop-invariant lane masks (no divergent branches: each costs exec-mask traffic)
+            T xm = up, xp = dn;
             if (XZ) {
                 xm = T(0);
                 xp = T(0);
             } else {
-                if (first_vec)
-                    xm = m.ishell_mem ? XL[pos] : sx * cc[0];
-                else
-                    xm = has_left ? up : (XLDS ? shx_last[wave > 0 ? wave - 1 : 0][pos] : XL[pos]);
-                if (last_vec)
-                    xp = m.ishell_mem ? XR[pos] : sx * cc[W - 1];
-                else
-                    xp = has_right ? dn : (XLDS ? shx_first[wave < 3 ? wave + 1 : 3][pos] : XR[pos]);
+                if (XLDS && multi_wave) {
+                    xm = has_left ? up : shx_last[wave > 0 ? wave - 1 : 0][pos];
+                    xp = has_right ? dn : shx_first[wave < 3 ? wave + 1 : 3][pos];
+                }
+                xm = left_mem ? XL[pos] : xm;
+                xp = right_mem ? XR[pos] : xp;
+                xm = mirror_l ? sx * cc[0] : xm;
+                xp = mirror_r ? sx * cc[W - 1] : xp;
             }
             const V km = X[c + 1][r + 2], kp = X[c + 3][r + 2];
             const V jm = X[c + 2][r + 1], jp = X[c + 2][r + 3];
@@ -890,15 +892,13 @@ __global__ void __launch_bounds__(256, SF_J2_WAVES) jacobi2_kernel(Geom g, Jacob
             const V yc = Y[rk + 1][rj + 1];
             const T up = lane_up(yc[W - 1]);
             const T dn = lane_dn(yc[0]);
-            T ym, yp;
-            if (first_vec)
-                ym = sx * yc[0];
-            else
+            T ym = up, yp = dn;
+            if (multi_wave) {
                 ym = has_left ? up : sh_last[wave > 0 ? wave - 1 : 0][rk * RJ + rj];
-            if (last_vec)
-                yp = sx * yc[W - 1];
-            else
                 yp = has_right ? dn : sh_first[wave < 3 ? wave + 1 : 3][rk * RJ + rj];
+            }
+            ym = first_vec ? sx * yc[0] : ym;
+            yp = last_vec ? sx * yc[W - 1] : yp;
             if (!active || kl >= ke || j > N) continue;
             V jm = Y[rk + 1][rj], jp = Y[rk + 1][rj + 2], km = Y[rk][rj + 1], kp = Y[rk + 2][rj + 1];
             if (wave_walls) {  // first-sweep set_bnd on the j / k walls
