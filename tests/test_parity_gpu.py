@@ -588,9 +588,10 @@ def test_invalid_arguments_are_rejected():
 
 # ---- size-independent properties at BASELINE.json's sizes (the oracle is too slow there) ---------
 
-@pytest.mark.parametrize("N", [256])
-def test_large_properties(N):
-    dtype = np.float32
+@pytest.mark.parametrize("N,dtype", [(256, np.float32), (512, np.float32), (512, np.float64)],
+                         ids=["256-f32", "512-f32", "512-f64"])
+def test_large_properties(N, dtype):
+    """configs[1], configs[2] and configs[4] of BASELINE.json (grid and precision; the oracle is too slow there)."""
     K = 20
     rng = np.random.RandomState(13)
     with make(N, dtype, K=K) as fs:
@@ -608,7 +609,7 @@ def test_large_properties(N):
         fs.dens_step()
         fs.sync()
         d = fs.download("dens")
-        assert np.all(d == np.float32(0.75))
+        assert np.all(d == dtype(0.75))
         fs.set_coefficients(DT, DIFF, VISC)
         # (3) Jacobi fixed point: x0 := c*x - a*sum(x_nb) makes x a fixed point up to rounding; instead
         # use linearity-free exact check: zero neighbours. x = 0, x0 = r  ->  one sweep gives r*inv exactly.
@@ -618,8 +619,8 @@ def test_large_properties(N):
         a, c = 0.25, 2.5
         fs.lin_solve(0, "dens", "dens0", a, c, 1)
         got = fs.download("dens")
-        inv = np.float32(1) / np.float32(c)
-        want = (r[1:-1, 1:-1, 1:-1] + np.float32(a) * np.float32(0)) * inv
+        inv = dtype(1) / dtype(c)
+        want = (r[1:-1, 1:-1, 1:-1] + dtype(a) * dtype(0)) * inv
         assert np.array_equal(got[1:-1, 1:-1, 1:-1], want)
         # shell = copy of the adjacent interior (b = 0)
         assert np.array_equal(got[0, 1:-1, 1:-1], got[1, 1:-1, 1:-1])
@@ -645,7 +646,7 @@ def test_large_properties(N):
             fs.sync()
             out.append({n: fs.download(n) for n in ("u", "v", "w", "dens")})
     for n in out[0]:
-        assert_same(out[1][n], out[0][n], f"256^3 P=4 vs P=1: {n}")
+        assert_same(out[1][n], out[0][n], f"{N}^3 P=4 vs P=1: {n}")
     # (6) mirror symmetry of a centred source (x -> N+1-x) is preserved by dens diffusion
     with make(N, dtype, K=6) as fs:
         src = np.zeros((N + 2,) * 3, dtype)
