@@ -659,11 +659,13 @@ def test_large_properties(N, dtype):
         assert np.array_equal(d, d[::-1, :, :]) and np.array_equal(d, d[:, ::-1, :]) and np.array_equal(d, d[:, :, ::-1])
 
 
-def test_config4_grid_eight_slabs_equal_one():
-    """configs[3] of BASELINE.json: the 1024^3 grid cut into eight k-slabs (logical slabs on one GPU: same kernels,
-    ghost planes and exchange schedule as eight ranks, copies instead of RCCL). lin_solve on rows of 256 vectors
-    (fused pairs through the overlapped mapping, two ghost planes) must equal the undecomposed solve bit for bit."""
-    N, K, dtype = 1024, 4, np.float32
+@pytest.mark.parametrize("N,dtype", [(1024, np.float32), (512, np.float64)], ids=["config4-1024-f32", "config5-512-f64"])
+def test_decomposed_configs_eight_slabs_equal_one(N, dtype):
+    """configs[3] and configs[4] of BASELINE.json: the 1024^3 fp32 / 512^3 fp64 grids cut into eight k-slabs (logical
+    slabs on one GPU: same kernels, ghost planes and exchange schedule as eight ranks, copies instead of RCCL).
+    lin_solve on rows of 256 vectors (fused pairs through the overlapped mapping, two ghost planes) and one full
+    step must equal the undecomposed run bit for bit."""
+    K = 4
     rng = np.random.RandomState(31)
     plane = rng.standard_normal((1, N + 2, N + 2)).astype(dtype)
     res = []
@@ -676,7 +678,7 @@ def test_config4_grid_eight_slabs_equal_one():
             fs.sync()
             res.append(fs.download("dens"))
     assert np.isfinite(res[0]).all() and res[0].std() > 0
-    assert_same(res[1], res[0], "1024^3 lin_solve, 8 slabs vs 1")
+    assert_same(res[1], res[0], f"{N}^3 lin_solve, 8 slabs vs 1")
     del res
 
     # one full vel_step + dens_step (K = 2) on the same grid; velocities small enough for the one-plane back-trace rule
@@ -684,7 +686,7 @@ def test_config4_grid_eight_slabs_equal_one():
     for P in (1, 8):
         with make(N, dtype, K=2, nslabs_local=P) as fs:
             for q, n in enumerate(NAMES):
-                scale = dtype(0.25 if n.startswith("dens") else 0.002)
+                scale = dtype(0.25 if n.startswith("dens") else 2.0 / N)
                 for k in range(N + 2):
                     fs.upload_planes(n, k, plane * (scale * dtype(1 + 0.0007 * ((k + 37 * q) % 101))))
             fs.vel_step()
@@ -693,7 +695,7 @@ def test_config4_grid_eight_slabs_equal_one():
             out.append({n: fs.download(n) for n in ("u", "w", "dens")})
     for n in out[0]:
         assert np.isfinite(out[0][n]).all()
-        assert_same(out[1][n], out[0][n], f"1024^3 full step, 8 slabs vs 1: {n}")
+        assert_same(out[1][n], out[0][n], f"{N}^3 full step, 8 slabs vs 1: {n}")
 
 
 def test_driver_frame_equals_config1_golden(tmp_path):
