@@ -170,8 +170,13 @@ def main():
     N = args.n if args.n > 0 else WEAK_GRID.get(world, 256 * world)
     assert N % world == 0, f"grid {N} not divisible by {world} ranks"
     nccl_id = sfdist.share_nccl_id(dist, S.nccl_unique_id)
+    # SF_BENCH_LOOPBACK=1 (with SF_FORCE_DEVICE=0): rehearsal of this file's multi-process path on a one-GPU box, where
+    # RCCL refuses two ranks on one device — every rank runs its own slab with SF_FLAG_LOOPBACK_HALO (halo messages
+    # become device-local copies, include/sfgpu.h). The line it prints is tagged and is not a result.
+    loopback = os.environ.get("SF_BENCH_LOOPBACK") == "1" and world > 1
+    kw = {"flags": 1} if loopback else {}
     fs = S.FluidSolver(N, dtype=args.dtype, iters=K, dt=dt, diff=diff, visc=visc, device=local_rank, rank=rank,
-                       nranks=world, nccl_id=nccl_id, nslabs_local=args.local_slabs)
+                       nranks=world, nccl_id=None if loopback else nccl_id, nslabs_local=args.local_slabs, **kw)
     kb, ke = fs.stored_planes()
     f = analytic_planes(N, kb, ke, dt, fs.np_dtype)
     for name, slot in (("u", "u"), ("v", "v"), ("w", "w"), ("dens", "dens"), ("su", "user0"), ("sv", "user1"),
@@ -233,6 +238,7 @@ def main():
             "vs_baseline": None,
             "dtype": args.dtype,
             "data": ("DRYRUN - no computation" if os.environ.get("SF_BENCH_DRYRUN") == "1"
+                     else "LOOPBACK REHEARSAL on shared devices - not a result" if loopback
                      else "synthetic (analytic fields of docs/SPEC.md §5, resident in HBM)"),
             "config": {"workload": f"{N}^3 {args.dtype}, K={K} Jacobi iters per lin_solve, vel_step+dens_step "
                                    f"with per-step source re-injection", "grid": N, "jacobi_iters": K,

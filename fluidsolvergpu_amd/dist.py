@@ -53,7 +53,21 @@ def init(backend="gloo"):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29531")
     if not dist.is_initialized():
-        dist.init_process_group(backend, rank=rank, world_size=world)
+        # gloo announces its connections on STDOUT ("[Gloo] Rank 0 is connected to ..."), and bench.py owes its caller
+        # exactly one JSON line there: while the group is set up (and its connections made, by a first barrier),
+        # file descriptor 1 points at stderr
+        import sys
+
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
     return dist
 
 

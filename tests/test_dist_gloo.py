@@ -60,6 +60,8 @@ def test_bench_multirank_plumbing_dryrun(world):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout
+    # nothing but that line on stdout (gloo's "[Gloo] Rank .. is connected" chatter is steered to stderr)
+    assert [ln for ln in r.stdout.splitlines() if ln.strip()] == lines, r.stdout
     d = json.loads(lines[0])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline"):
