@@ -95,6 +95,7 @@ public:
     virtual double copy_bandwidth(size_t bytes, int reps) = 0;
     virtual void layout_info(int* pitch, int* planes, size_t* bytes) const = 0;
     virtual void schedule_info(int* trap, int* measured) const = 0;
+    virtual void transport_info(int* transport, long* groups) const = 0;
     virtual int lin_solve_launches(int iters) const = 0;
     virtual void snapshot(const int* fields, int nfields) = 0;
     virtual void snapshot_read(int index, void* host) = 0;
@@ -137,6 +138,9 @@ public:
         P_ = nranks_ * L_;
         SF_REQUIRE(N_ % P_ == 0, "N must be divisible by nranks*nslabs_local");
         loopback_ = (p.flags & SF_FLAG_LOOPBACK_HALO) != 0;
+        rccl_self_ = (p.flags & SF_FLAG_RCCL_SELF) != 0;
+        SF_REQUIRE(!rccl_self_ || (nranks_ == 1 && L_ >= 2 && !loopback_),
+                   "SF_FLAG_RCCL_SELF needs nranks == 1, nslabs_local >= 2 and no loopback flag");
         SF_REQUIRE(nranks_ == 1 || loopback_ || p.nccl_id != nullptr, "nccl_id required when nranks > 1");
         set_coefficients(p.dt, p.diff, p.visc);
 
@@ -189,7 +193,7 @@ public:
             // decomposed grid). halo_done keeps it when the ghost planes are written by another GPU through RCCL.
             const unsigned ev_local =
                 hipEventDisableTiming | (env_int("SF_EVENT_FENCE", 0) ? 0u : (unsigned)hipEventDisableSystemFence);
-            const unsigned ev_halo = (nranks_ > 1 && !loopback_) ? (unsigned)hipEventDisableTiming : ev_local;
+            const unsigned ev_halo = ((nranks_ > 1 && !loopback_) || rccl_self_) ? (unsigned)hipEventDisableTiming : ev_local;
             SF_HIP(hipEventCreateWithFlags(&sl.cs_mark, ev_local));
             sl.cur = sl.cs;
             {
@@ -228,6 +232,12 @@ public:
             static_assert(sizeof(ncclUniqueId) <= SF_NCCL_ID_BYTES, "ncclUniqueId larger than ABI slot");
             std::memcpy(&id, p.nccl_id, sizeof id);
             SF_NCCL(ncclCommInitRank(&comm_, nranks_, id, rank_));
+        } else if (rccl_self_) {
+            // a real communicator of one rank: the logical slabs' ghost planes travel as grouped ncclSend / ncclRecv
+            // to self (see exchange()), so the RCCL data plane runs on a one-GPU box
+            ncclUniqueId id;
+            SF_NCCL(ncclGetUniqueId(&id));
+            SF_NCCL(ncclCommInitRank(&comm_, 1, id, 0));
         }
         kchunk_ = env_int("SF_KCHUNK", 0);
         jacobi_mode_ = env_int("SF_JACOBI", 2);
@@ -253,11 +263,11 @@ public:
         // (2.4 MB per direction and pair at 512^2: tens of microseconds) the boundary chain is, so the default there
         // keeps B at its minimum size (0 = off) unless the measurement at the end of this constructor
         // (tune_schedule) says otherwise. SF_TRAP overrides and switches the measurement off.
-        trap_m_ = env_int("SF_TRAP", nranks_ > 1 ? 0 : 5);  // pairs per trapezoid block of a decomposed lin_solve (<= 1: off)
+        trap_m_ = env_int("SF_TRAP", (nranks_ > 1 || rccl_self_) ? 0 : 5);  // pairs per trapezoid block of a decomposed lin_solve (<= 1: off)
         strip_mode_ = env_int("SF_STRIP", 0);  // 0 heuristic, 1 dense, 2 wave-aligned row strips in the fused kernel
         graphs_ = env_int("SF_GRAPH", 0) != 0 && P_ == 1;
         SF_HIP(hipDeviceSynchronize());
-        if (nranks_ > 1 && std::getenv("SF_TRAP") == nullptr && env_int("SF_AUTOTUNE", 1)) tune_schedule();
+        if ((nranks_ > 1 || rccl_self_) && std::getenv("SF_TRAP") == nullptr && env_int("SF_AUTOTUNE", 1)) tune_schedule();
     }
 
     // Which trapezoid depth suits THIS machine's halo latency (see the comment at trap_m_)? Times a 20-sweep
@@ -732,12 +742,10 @@ public:
         SF_HIP(hipSetDevice(device_));
         bytes = (bytes + 4095) / 4096 * 4096;
         if (copy_bytes_ != bytes) {
-            if (tr_pos_) (void)hipFree(tr_pos_);
-        if (tr_dens_) (void)hipFree(tr_dens_);
-        if (tr_speed_) (void)hipFree(tr_speed_);
-        if (copy_src_) (void)hipFree(copy_src_);
+            if (copy_src_) (void)hipFree(copy_src_);
             if (copy_dst_) (void)hipFree(copy_dst_);
             copy_src_ = copy_dst_ = nullptr;
+            copy_bytes_ = 0;
             SF_HIP(hipMalloc(&copy_src_, bytes));
             SF_HIP(hipMalloc(&copy_dst_, bytes));
             SF_HIP(hipMemset(copy_src_, 1, bytes));
@@ -750,7 +758,9 @@ public:
         double best_ms = 1e30;
         for (int r = 0; r <= reps; ++r) {
             SF_HIP(hipEventRecord(t0_, st));
-            hipLaunchKernelGGL(sfk::copy16_kernel, dim3(stream_grid(n)), dim3(256), 0, st,
+            // one thread per 16 bytes, the grid in memory order: the shape that reaches 6.2-6.3 TB/s here
+            // (tools/membench.hip); a grid-stride loop over a few thousand blocks stays at 5.0-5.9
+            hipLaunchKernelGGL(sfk::copy16_kernel, dim3((unsigned)ceil_div(n, 256L)), dim3(256), 0, st,
                                (const float4*)copy_src_, (float4*)copy_dst_, n);
             SF_HIP(hipEventRecord(t1_, st));
             SF_HIP(hipEventSynchronize(t1_));
@@ -849,6 +859,11 @@ public:
     void schedule_info(int* trap, int* measured) const override {
         if (trap) *trap = trap_m_ > 1 ? trap_m_ : 0;
         if (measured) *measured = (tuned_trap_ >= 0 ? 1 : 0) | (tuned_split_ >= 0 ? 2 : 0) | (split_fields_ == 0 ? 4 : 0);
+    }
+    void transport_info(int* transport, long* groups) const override {
+        if (transport)
+            *transport = P_ == 1 ? 0 : (rccl_self_ ? 3 : (loopback_ ? 4 : (nranks_ > 1 ? 2 : 1)));
+        if (groups) *groups = rccl_groups_;
     }
     void layout_info(int* pitch, int* planes, size_t* bytes) const override {
         if (pitch) *pitch = px_;
@@ -1044,6 +1059,10 @@ private:
         const size_t bytes = gcount * sizeof(T);
         const size_t send_lo = (size_t)G_ * plane_, send_hi = (size_t)nzl_ * plane_;
         const size_t recv_lo = 0, recv_hi = (size_t)(G_ + nzl_) * plane_;
+        if (rccl_self_) {
+            exchange_rccl_self<NF>(fields, gcount, send_lo, send_hi, recv_lo, recv_hi);
+            return;
+        }
         for (int s = 0; s < L_; ++s) {
             Slab& sl = slabs_[s];
             SF_HIP(hipStreamWaitEvent(sl.hs, sl.boundary_done, 0));
@@ -1107,12 +1126,57 @@ private:
                     }
                 }
                 SF_NCCL(ncclGroupEnd());
+                ++rccl_groups_;
             }
             SF_HIP(hipEventRecord(sl.halo_done, sl.hs));
         }
         // consumers: the next boundary launch reads my ghosts, and neighbours that pulled from my planes must be
         // done before I overwrite them two sweeps later. The compute stream only waits when it runs a
         // whole-field operator (join()).
+        for (int s = 0; s < L_; ++s) {
+            Slab& sl = slabs_[s];
+            SF_HIP(hipStreamWaitEvent(sl.bs, sl.halo_done, 0));
+            if (s > 0) SF_HIP(hipStreamWaitEvent(sl.bs, slabs_[s - 1].halo_done, 0));
+            if (s < L_ - 1) SF_HIP(hipStreamWaitEvent(sl.bs, slabs_[s + 1].halo_done, 0));
+        }
+        pending_join_ = true;
+    }
+
+    // SF_FLAG_RCCL_SELF: the ghost planes of the L logical slabs travel through a real RCCL communicator (one rank,
+    // this GPU) as grouped ncclSend / ncclRecv to self — the calls, datatype, counts, buffer offsets, stream choice
+    // (each slab's halo stream, which is its boundary stream under SF_HALO_STREAM=2 as in production) and the
+    // system-scope halo_done event of the multi-process branch of exchange(). RCCL matches the sends and the receives
+    // of one peer in issue order, so every transfer is issued as the pair (send from the owner's planes, receive into
+    // the neighbour's ghost planes); one group spans all slabs because a send to self needs its receive in the same
+    // group.
+    template <int NF>
+    void exchange_rccl_self(const int (&fields)[NF], size_t gcount, size_t send_lo, size_t send_hi, size_t recv_lo,
+                            size_t recv_hi) {
+        const ncclDataType_t dt = sizeof(T) == 4 ? ncclFloat : ncclDouble;
+        for (int s = 0; s < L_; ++s) {
+            Slab& sl = slabs_[s];
+            SF_HIP(hipStreamWaitEvent(sl.hs, sl.boundary_done, 0));
+            if (s > 0) SF_HIP(hipStreamWaitEvent(sl.hs, slabs_[s - 1].boundary_done, 0));
+            if (s < L_ - 1) SF_HIP(hipStreamWaitEvent(sl.hs, slabs_[s + 1].boundary_done, 0));
+        }
+        SF_NCCL(ncclGroupStart());
+        for (int s = 0; s + 1 < L_; ++s) {
+            Slab& lo = slabs_[s];
+            Slab& hi = slabs_[s + 1];
+            for (int f = 0; f < NF; ++f) {
+                T* a = lo.field[fields[f]];
+                T* b = hi.field[fields[f]];
+                // upward: last interior planes of slab s -> low ghost planes of slab s+1
+                SF_NCCL(ncclSend(a + send_hi, gcount, dt, 0, comm_, lo.hs));
+                SF_NCCL(ncclRecv(b + recv_lo, gcount, dt, 0, comm_, hi.hs));
+                // downward: first interior planes of slab s+1 -> high ghost planes of slab s
+                SF_NCCL(ncclSend(b + send_lo, gcount, dt, 0, comm_, hi.hs));
+                SF_NCCL(ncclRecv(a + recv_hi, gcount, dt, 0, comm_, lo.hs));
+            }
+        }
+        SF_NCCL(ncclGroupEnd());
+        ++rccl_groups_;
+        for (int s = 0; s < L_; ++s) SF_HIP(hipEventRecord(slabs_[s].halo_done, slabs_[s].hs));
         for (int s = 0; s < L_; ++s) {
             Slab& sl = slabs_[s];
             SF_HIP(hipStreamWaitEvent(sl.bs, sl.halo_done, 0));
@@ -1606,7 +1670,8 @@ private:
     long plane_ = 0, field_elems_ = 0;
     std::vector<Slab> slabs_;
     ncclComm_t comm_ = nullptr;
-    bool loopback_ = false;
+    bool loopback_ = false, rccl_self_ = false;
+    long rccl_groups_ = 0;  // RCCL send/recv groups issued so far (sf_schedule_info: proof the transport ran)
     hipEvent_t t0_ = nullptr, t1_ = nullptr;
     T* tr_pos_ = nullptr;
     T* tr_dens_ = nullptr;
@@ -1763,6 +1828,9 @@ int sf_snapshot_read(sf_ctx* ctx, int index, void* host) {
     } catch (const Failure& f) {
         ctx->snap_err = f.msg;
         return f.code;
+    } catch (const std::exception& e) {  // e.g. std::bad_alloc: nothing may cross the C ABI
+        ctx->snap_err = e.what();
+        return SF_ERR_INVALID;
     }
 }
 int sf_tracers_set(sf_ctx* ctx, int n, const void* xyz) {
@@ -1814,6 +1882,11 @@ int sf_layout_info(const sf_ctx* ctx, int* row_pitch, int* planes_per_slab, size
 int sf_schedule_info(const sf_ctx* ctx, int* trapezoid_pairs, int* measured) {
     if (!ctx || !ctx->impl) return SF_ERR_INVALID;
     ctx->impl->schedule_info(trapezoid_pairs, measured);
+    return SF_OK;
+}
+int sf_transport_info(const sf_ctx* ctx, int* transport, long* rccl_groups) {
+    if (!ctx || !ctx->impl) return SF_ERR_INVALID;
+    ctx->impl->transport_info(transport, rccl_groups);
     return SF_OK;
 }
 

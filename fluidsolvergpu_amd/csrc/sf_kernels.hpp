@@ -1630,8 +1630,8 @@ __global__ void __launch_bounds__(256) halo_copy_kernel(HaloCopyArgs A) {
 // float4 copy used to quote the achievable HBM rate in the same run as the solver numbers.
 __global__ void __launch_bounds__(256) copy16_kernel(const float4* __restrict__ src,
                                                      float4* __restrict__ dst, long n) {
-    const long stride = (long)gridDim.x * blockDim.x;
-    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += stride) dst[q] = src[q];
+    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < n) dst[q] = src[q];
 }
 
 }  // namespace sfk

@@ -22,6 +22,8 @@ FIELD_IDS = {"u": 0, "v": 1, "w": 2, "u0": 3, "v0": 4, "w0": 5, "dens": 6, "dens
              "user0": 8, "user1": 9, "user2": 10, "user3": 11}
 FIELD_NAMES = ("u", "v", "w", "u0", "v0", "w0", "dens", "dens0")
 NCCL_ID_BYTES = 128
+SF_FLAG_LOOPBACK_HALO, SF_FLAG_RCCL_SELF = 1, 2
+TRANSPORTS = ("none", "copy", "rccl", "rccl-self", "loopback")
 
 # every symbol include/sfgpu.h declares (tests check that the library exports all of them)
 ABI_SYMBOLS = (
@@ -30,7 +32,7 @@ ABI_SYMBOLS = (
     "dens_step", "sf_add_source", "sf_set_bnd", "sf_lin_solve", "sf_diffuse", "sf_advect", "sf_project",
     "sf_set_iters", "sf_set_coefficients", "sf_sync", "sf_last_error", "sf_timer_start", "sf_timer_stop",
     "sf_measure_copy_bandwidth", "sf_layout_info", "sf_schedule_info", "sf_lin_solve_launches", "sf_snapshot", "sf_snapshot_read",
-    "sf_tracers_set", "sf_tracers_advect", "sf_tracers_get", "sf_bind_sources",
+    "sf_tracers_set", "sf_tracers_advect", "sf_tracers_get", "sf_bind_sources", "sf_transport_info",
 )
 
 
@@ -81,6 +83,7 @@ lib.sf_tracers_advect.argtypes = [_ctx]
 lib.sf_tracers_get.argtypes = [_ctx, C.c_void_p, C.c_void_p, C.c_void_p]
 lib.sf_layout_info.argtypes = [_ctx, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_size_t)]
 lib.sf_schedule_info.argtypes = [_ctx, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+lib.sf_transport_info.argtypes = [_ctx, C.POINTER(C.c_int), C.POINTER(C.c_long)]
 
 
 class SfError(RuntimeError):
@@ -283,6 +286,12 @@ class FluidSolver:
         m = measured.value
         return {"trapezoid_pairs": trap.value, "measured": bool(m & 1), "fields_measured": bool(m & 2),
                 "fields_per_launch": 3 if (m & 4) else 1}
+
+    def transport_info(self):
+        """Halo transport of this context and how many RCCL send/recv groups it has issued so far."""
+        t, g = C.c_int(), C.c_long()
+        self._ck(lib.sf_transport_info(self._h, C.byref(t), C.byref(g)))
+        return {"transport": TRANSPORTS[t.value], "rccl_groups": g.value}
 
     def layout_info(self):
         pitch, planes, nbytes = C.c_int(), C.c_int(), C.c_size_t()

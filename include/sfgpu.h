@@ -69,6 +69,15 @@ typedef struct sf_params {
  * next to the slab boundaries are then meaningless. */
 #define SF_FLAG_LOOPBACK_HALO 1
 
+/* Verification aid for the inter-process data plane on a ONE-GPU box (RCCL refuses two ranks on one device):
+ * nranks == 1, nslabs_local >= 2, and the ghost planes of the logical slabs travel through a real single-rank RCCL
+ * communicator as grouped ncclSend / ncclRecv to self — the same calls, counts, datatypes, buffer offsets, streams
+ * and system-scope halo event as the multi-process exchange (whose role is that of the reference's 2-GPU buffer
+ * exchange, solver-unidyn.cu:396-470) — instead of the device-local copy kernel. Results are bit-identical to the
+ * copy transport and to the undecomposed solve; sf_create also runs the schedule measurement and its all-reduce
+ * vote over that communicator, as a multi-process context does. */
+#define SF_FLAG_RCCL_SELF 2
+
 /* Library / build identification ("sfgpu <ver> gfx950 hip"). */
 const char* sf_version(void);
 const char* sf_status_string(int status);
@@ -175,6 +184,11 @@ int sf_layout_info(const sf_ctx* ctx, int* row_pitch, int* planes_per_slab, size
  * size); `measured` bit 0: sf_create measured the depth on this machine (else default / SF_TRAP), bit 1: it also
  * measured "u,v,w one field at a time" against "three fields per launch", bit 2: the three-field form is in use. */
 int sf_schedule_info(const sf_ctx* ctx, int* trapezoid_pairs, int* measured);
+
+/* Which halo transport this context uses and how often it ran: *transport = 0 none (one slab), 1 device-local copy
+ * kernel between logical slabs, 2 RCCL send/recv between processes, 3 RCCL send/recv to self (SF_FLAG_RCCL_SELF),
+ * 4 loopback copies (SF_FLAG_LOOPBACK_HALO); *rccl_groups = ncclGroupEnd calls of the halo exchange issued so far. */
+int sf_transport_info(const sf_ctx* ctx, int* transport, long* rccl_groups);
 
 #ifdef __cplusplus
 }

@@ -41,6 +41,25 @@ def assert_same(got, want, what):
 
 SIZES = [1, 2, 3, 5, 8, 13, 16, 31, 34]
 DTYPES = [np.float32, np.float64]
+# Halo transport between the logical slabs of one context: the device-local copy kernel, or a real single-rank RCCL
+# communicator with grouped ncclSend / ncclRecv to self (SF_FLAG_RCCL_SELF: the calls, streams and fences of the
+# multi-process exchange, executed on the one GPU a test box has).
+TRANSPORTS = ["copy", "rccl-self"]
+
+
+def slab_kw(transport, P):
+    return {"nslabs_local": P, "flags": 2} if (transport == "rccl-self" and P >= 2) else {"nslabs_local": P}
+
+
+def check_transport(fs, transport, P):
+    """The context really used the transport the test asked for (and RCCL groups were issued)."""
+    info = fs.transport_info()
+    if P < 2:
+        assert info["transport"] == "none"
+    elif transport == "rccl-self":
+        assert info["transport"] == "rccl-self" and info["rccl_groups"] > 0, info
+    else:
+        assert info["transport"] == "copy" and info["rccl_groups"] == 0, info
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "f64"])
@@ -220,16 +239,18 @@ def small_velocity(f, N, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "f64"])
+@pytest.mark.parametrize("transport", TRANSPORTS)
 @pytest.mark.parametrize("N,P", [(2, 2), (4, 4), (8, 2), (8, 8), (12, 3), (16, 4), (32, 2), (34, 17)])
-def test_slabs_full_step_bit_identical(N, P, dtype):
+def test_slabs_full_step_bit_identical(N, P, transport, dtype):
     K = 5
     f = small_velocity(rand_fields(N, dtype, 9), N, dtype)
-    with make(N, dtype, K=K, nslabs_local=P) as fs:
+    with make(N, dtype, K=K, **slab_kw(transport, P)) as fs:
         for n in NAMES:
             fs.upload(n, f[n])
         fs.vel_step()
         fs.dens_step()
         fs.sync()
+        check_transport(fs, transport, P)
         got = {n: fs.download(n) for n in NAMES}
     O.step(N, f, dtype(DT), dtype(DIFF), dtype(VISC), K)
     for n in NAMES:
@@ -237,13 +258,14 @@ def test_slabs_full_step_bit_identical(N, P, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "f64"])
+@pytest.mark.parametrize("transport", TRANSPORTS)
 @pytest.mark.parametrize("N,P,K,steps", [(64, 2, 7, 2), (64, 8, 6, 1), (48, 4, 4, 2), (128, 4, 5, 1)])
-def test_slabs_fused_pairs_two_ghost_planes(N, P, K, steps, dtype):
+def test_slabs_fused_pairs_two_ghost_planes(N, P, K, steps, transport, dtype):
     """N % vector width == 0 and >= 2 planes per slab: sweep pairs are fused across slab boundaries (two ghost
     planes, one exchange per pair, div recomputed on the first ghost plane). Must still equal the oracle."""
     f = small_velocity(rand_fields(N, dtype, 21), N, dtype)
     src = {n: f[n].copy() for n in ("u0", "v0", "w0", "dens0")}
-    with make(N, dtype, K=K, nslabs_local=P) as fs:
+    with make(N, dtype, K=K, **slab_kw(transport, P)) as fs:
         for n in NAMES:
             fs.upload(n, f[n])
         for s in range(steps):
@@ -253,6 +275,7 @@ def test_slabs_fused_pairs_two_ghost_planes(N, P, K, steps, dtype):
             fs.vel_step()
             fs.dens_step()
         fs.sync()
+        check_transport(fs, transport, P)
         got = {n: fs.download(n) for n in NAMES}
     for s in range(steps):
         if s > 0:
@@ -263,9 +286,10 @@ def test_slabs_fused_pairs_two_ghost_planes(N, P, K, steps, dtype):
         assert_same(got[n], f[n], f"P={P} fused: {n}")
 
 
+@pytest.mark.parametrize("transport", TRANSPORTS)
 @pytest.mark.parametrize("prio", ["0", "1"])
 @pytest.mark.parametrize("N,P,K", [(128, 2, 6), (128, 8, 5), (192, 4, 4), (256, 8, 3)])
-def test_slabs_stress_against_single_slab(N, P, K, prio, monkeypatch):
+def test_slabs_stress_against_single_slab(N, P, K, prio, transport, monkeypatch):
     """Timing-sensitive check of the halo overlap: large interior launches run concurrently with the exchange.
     The decomposed run must equal the single-slab GPU run bit for bit, with the halo stream at normal and at
     highest priority (the latter exposed a missing dependency during development), repeated."""
@@ -274,7 +298,7 @@ def test_slabs_stress_against_single_slab(N, P, K, prio, monkeypatch):
     f = small_velocity(rand_fields(N, dtype, 40 + P), N, dtype)
 
     def run(nslabs):
-        with make(N, dtype, K=K, nslabs_local=nslabs) as fs:
+        with make(N, dtype, K=K, **slab_kw(transport, nslabs)) as fs:
             for n in NAMES:
                 fs.upload(n, f[n])
             for _ in range(2):
@@ -282,6 +306,7 @@ def test_slabs_stress_against_single_slab(N, P, K, prio, monkeypatch):
                 fs.vel_step()
                 fs.dens_step()
             fs.sync()
+            check_transport(fs, transport, nslabs)
             return {n: fs.download(n) for n in ("u", "v", "w", "dens")}
 
     want = run(1)
@@ -293,7 +318,8 @@ def test_slabs_stress_against_single_slab(N, P, K, prio, monkeypatch):
 
 @pytest.mark.parametrize("N,P,K,trap", [(128, 2, 20, "5"), (128, 4, 20, "3"), (160, 4, 12, "10"), (320, 2, 20, "5"),
                                         (128, 2, 20, "0"), (64, 2, 9, "4")])
-def test_slabs_trapezoid_schedule(N, P, K, trap, monkeypatch):
+@pytest.mark.parametrize("transport", TRANSPORTS)
+def test_slabs_trapezoid_schedule(N, P, K, trap, transport, monkeypatch):
     """lin_solve on a decomposed grid: the boundary launch grows by two planes per pair so that consecutive interior
     launches need no cross-stream wait (SF_TRAP pairs per block; 0 = off). Long solves (several blocks, a resync in
     between, odd K, a row width that takes the overlapped mapping) must equal the single-slab GPU run bit for bit."""
@@ -302,7 +328,7 @@ def test_slabs_trapezoid_schedule(N, P, K, trap, monkeypatch):
     f = small_velocity(rand_fields(N, dtype, 70 + P), N, dtype)
 
     def run(nslabs):
-        with make(N, dtype, K=K, nslabs_local=nslabs) as fs:
+        with make(N, dtype, K=K, **slab_kw(transport, nslabs)) as fs:
             for n in NAMES:
                 fs.upload(n, f[n])
             fs.vel_step()
@@ -317,8 +343,9 @@ def test_slabs_trapezoid_schedule(N, P, K, trap, monkeypatch):
             assert_same(got[n], want[n], f"N={N} P={P} K={K} trap={trap} rep={rep}: {n}")
 
 
+@pytest.mark.parametrize("transport", TRANSPORTS)
 @pytest.mark.parametrize("N,P,K", [(128, 2, 8), (96, 4, 5), (64, 8, 4), (160, 2, 20)])
-def test_slabs_halo_on_the_boundary_stream(N, P, K, monkeypatch):
+def test_slabs_halo_on_the_boundary_stream(N, P, K, transport, monkeypatch):
     """One slab per process issues its halo messages on the boundary stream (no cross-stream hand-over in the chain
     boundary launch -> message -> next boundary launch). SF_HALO_STREAM=2 applies the same stream sharing to the
     logical slabs of one process, where the result can be checked: bit-identical to the single-slab run, with bound
@@ -328,7 +355,7 @@ def test_slabs_halo_on_the_boundary_stream(N, P, K, monkeypatch):
     f = small_velocity(rand_fields(N, dtype, 80 + P), N, dtype)
 
     def run(nslabs, bound):
-        with make(N, dtype, K=K, nslabs_local=nslabs) as fs:
+        with make(N, dtype, K=K, **slab_kw(transport, nslabs)) as fs:
             for n in NAMES:
                 fs.upload(n, f[n])
             if bound:
@@ -339,6 +366,7 @@ def test_slabs_halo_on_the_boundary_stream(N, P, K, monkeypatch):
                 fs.vel_step()
                 fs.dens_step()
             fs.sync()
+            check_transport(fs, transport, nslabs)
             return {n: fs.download(n) for n in ("u", "v", "w", "dens")}
 
     for bound in (False, True):
@@ -485,6 +513,40 @@ def test_tracers(N, dtype):
     assert_same(got_pos, want, "tracer positions")
     assert_same(got_d, want_d, "tracer density sample")
     assert_same(got_s, want_s, "tracer speed sample")
+
+
+def test_tracers_survive_the_copy_bandwidth_probe():
+    """sf_tracers_set -> sf_measure_copy_bandwidth (two sizes: the probe re-allocates its buffers) -> sf_tracers_advect
+    -> sf_tracers_get. The probe once freed the tracer arrays (a mis-pasted block): kernels then ran on freed memory
+    that the probe's own buffers could re-use. The tracers must come out exactly as the oracle's."""
+    N, dtype = 16, np.float32
+    rng = np.random.RandomState(5)
+    f = rand_fields(N, dtype, 33, scale=0.5)
+    n = 50000
+    pos = rng.uniform(0.5, N + 0.5, size=(n, 3)).astype(dtype)
+    with make(N, dtype) as fs:
+        for k in ("u", "v", "w", "dens"):
+            fs.upload(k, f[k])
+        fs.tracers_set(pos)
+        fs.tracers_advect()
+        assert fs.copy_bandwidth_gbps(8 << 20, 2) > 0
+        assert fs.copy_bandwidth_gbps(32 << 20, 2) > 0
+        fs.tracers_advect()
+        got_pos, got_d, got_s = fs.tracers_get()
+        fs.tracers_set(pos[:100])  # re-setting frees the old arrays exactly once
+        assert fs.copy_bandwidth_gbps(8 << 20, 1) > 0
+        fs.tracers_advect()
+        got2, _, _ = fs.tracers_get()
+    want = pos.copy()
+    for _ in range(2):
+        O.tracers_advect(want, f["u"], f["v"], f["w"], dtype(DT))
+    want_d, want_s = O.tracers_sample(want, f["dens"], f["u"], f["v"], f["w"])
+    assert_same(got_pos, want, "tracer positions after the bandwidth probe")
+    assert_same(got_d, want_d, "tracer density sample after the bandwidth probe")
+    assert_same(got_s, want_s, "tracer speed sample after the bandwidth probe")
+    want2 = pos[:100].copy()
+    O.tracers_advect(want2, f["u"], f["v"], f["w"], dtype(DT))
+    assert_same(got2, want2, "re-set tracers")
 
 
 @pytest.mark.parametrize("P", [1, 4])
@@ -667,29 +729,34 @@ def test_large_properties(N, dtype):
 @pytest.mark.parametrize("N,dtype", [(1024, np.float32), (512, np.float64)], ids=["config4-1024-f32", "config5-512-f64"])
 def test_decomposed_configs_eight_slabs_equal_one(N, dtype):
     """configs[3] and configs[4] of BASELINE.json: the 1024^3 fp32 / 512^3 fp64 grids cut into eight k-slabs (logical
-    slabs on one GPU: same kernels, ghost planes and exchange schedule as eight ranks, copies instead of RCCL).
+    slabs on one GPU: same kernels, ghost planes and exchange schedule as eight ranks), with the ghost planes moved by
+    the copy kernel and by RCCL send/recv through a single-rank communicator (the transport of the eight-rank run).
     lin_solve on rows of 256 vectors (fused pairs through the overlapped mapping, two ghost planes) and one full
     step must equal the undecomposed run bit for bit."""
     K = 4
     rng = np.random.RandomState(31)
     plane = rng.standard_normal((1, N + 2, N + 2)).astype(dtype)
     res = []
-    for P in (1, 8):
-        with make(N, dtype, K=K, nslabs_local=P) as fs:
+    for P, transport in ((1, "copy"), (8, "copy"), (8, "rccl-self")):
+        with make(N, dtype, K=K, **slab_kw(transport, P)) as fs:
             for k in range(N + 2):
                 fs.upload_planes("dens", k, plane * dtype(1 + 0.001 * k))
                 fs.upload_planes("dens0", k, plane * dtype(0.5 - 0.0005 * k))
             fs.lin_solve(0, "dens", "dens0", 0.3, 2.8, K)
             fs.sync()
+            check_transport(fs, transport, P)
+            if transport == "rccl-self":  # sf_create measured the launch schedule over the communicator
+                assert fs.schedule_info()["measured"]
             res.append(fs.download("dens"))
     assert np.isfinite(res[0]).all() and res[0].std() > 0
-    assert_same(res[1], res[0], f"{N}^3 lin_solve, 8 slabs vs 1")
+    assert_same(res[1], res[0], f"{N}^3 lin_solve, 8 slabs (copy) vs 1")
+    assert_same(res[2], res[0], f"{N}^3 lin_solve, 8 slabs (rccl-self) vs 1")
     del res
 
     # one full vel_step + dens_step (K = 2) on the same grid; velocities small enough for the one-plane back-trace rule
     out = []
-    for P in (1, 8):
-        with make(N, dtype, K=2, nslabs_local=P) as fs:
+    for P, transport in ((1, "copy"), (8, "copy"), (8, "rccl-self")):
+        with make(N, dtype, K=2, **slab_kw(transport, P)) as fs:
             for q, n in enumerate(NAMES):
                 scale = dtype(0.25 if n.startswith("dens") else 2.0 / N)
                 for k in range(N + 2):
@@ -697,10 +764,12 @@ def test_decomposed_configs_eight_slabs_equal_one(N, dtype):
             fs.vel_step()
             fs.dens_step()
             fs.sync()
+            check_transport(fs, transport, P)
             out.append({n: fs.download(n) for n in ("u", "w", "dens")})
     for n in out[0]:
         assert np.isfinite(out[0][n]).all()
-        assert_same(out[1][n], out[0][n], f"{N}^3 full step, 8 slabs vs 1: {n}")
+        assert_same(out[1][n], out[0][n], f"{N}^3 full step, 8 slabs (copy) vs 1: {n}")
+        assert_same(out[2][n], out[0][n], f"{N}^3 full step, 8 slabs (rccl-self) vs 1: {n}")
 
 
 def test_driver_frame_equals_config1_golden(tmp_path):
