@@ -266,6 +266,12 @@ public:
         trap_m_ = env_int("SF_TRAP", (nranks_ > 1 || rccl_self_) ? 0 : 5);  // pairs per trapezoid block of a decomposed lin_solve (<= 1: off)
         strip_mode_ = env_int("SF_STRIP", 0);  // 0 heuristic, 1 dense, 2 wave-aligned row strips in the fused kernel
         graphs_ = env_int("SF_GRAPH", 0) != 0 && P_ == 1;
+        march_k_ = env_int("SF_MARCH", 1);
+        march_tj_ = env_int("SF_MARCH_TJ", 6);
+        march_kc_ = env_int("SF_MARCH_KC", 0);
+        march_wg_per_cu_ = env_int("SF_MARCH_WGCU", 0);  // workgroups per CU assumed by the chunk heuristic (0: by TJ)
+        march_min_planes_ = env_int("SF_MARCH_MINP", 12);
+        march_ahead_ = env_int("SF_MARCH_AHEAD", 0);
         SF_HIP(hipDeviceSynchronize());
         if ((nranks_ > 1 || rccl_self_) && std::getenv("SF_TRAP") == nullptr && env_int("SF_AUTOTUNE", 1)) tune_schedule();
     }
@@ -1403,10 +1409,77 @@ private:
                            sl.geom, A, kb, ke, m, kc);
     }
 
+    // Register-resident k-marching pair kernel (sfk::jacobi2k_kernel): the plain pairs of a solve on plane ranges
+    // long enough to march. SF_MARCH=0 switches it off; SF_MARCH_TJ (2, 4, 8) rows per lane; SF_MARCH_KC planes per chunk.
+    bool can_march_k(int nplanes, bool first) const {
+        return march_k_ != 0 && !first && ishell_skip_ && split_ == INT_MAX && nplanes >= march_min_planes_ && !x_is_zero_;
+    }
+
+    template <int NF, bool NT, int TJ, int WL>
+    void launch_march_k(Slab& sl, const sfk::JacobiArgs<T, NF>& A, int kb, int ke, bool last) {
+        const int nvec = N_ / WL;
+        sfk::MarchMap m{};
+        m.nrg = ceil_div(N_, TJ);
+        const long items = (long)m.nrg * nvec;
+        m.ncol = (int)ceil_div(items, (long)sfk::SF_OVL_OUT);
+        const int wgs = ceil_div(m.ncol, 4);
+        m.band = ceil_div(wgs, 8);
+        m.nvec_magic = nvec > 1 ? 0xFFFFFFFFu / (unsigned)nvec + 1u : 0u;
+        const int np = ke - kb;
+        // chunks: as long as possible (a chunk pays 2 extra first-sweep planes and 4 extra planes of x), but enough
+        // workgroups to fill the chip a whole number of times
+        int nchunk;
+        if (march_kc_ > 0 || np >= 64) {
+            // measured (512^3, 256^3 fp32): 32-plane chunks beat the "fill the chip a whole number of times" choice
+            nchunk = ceil_div(np, march_kc_ > 0 ? march_kc_ : 32);
+        } else {
+            const long cap = (long)num_cu_ * (march_wg_per_cu_ > 0 ? march_wg_per_cu_ : (TJ <= 2 ? 4 : 2));
+            const int max_chunks = std::max(1, np / 8);
+            double best = -1;
+            nchunk = 1;
+            for (int c = 1; c <= max_chunks; ++c) {
+                const int kc = ceil_div(np, c);
+                const long total = (long)wgs * NF * ceil_div(np, kc);
+                const long rounds = ceil_div(total, cap);
+                const double tm = (double)rounds * (kc + 4);  // time ~ rounds x (kc + 4) steps; prefer the shortest
+                if (best < 0 || tm < best * 0.999) {
+                    best = tm;
+                    nchunk = c;
+                }
+            }
+        }
+        m.kc = ceil_div(np, nchunk);
+        nchunk = ceil_div(np, m.kc);
+        const dim3 nb(8u, (unsigned)m.band, (unsigned)(nchunk * NF));
+        if (last)  // the last sweep of the solve writes the i = 0 / N+1 shell cells
+            launch_k(sl, sfk::jacobi2k_kernel<T, NF, WL, NT, TJ, true>, nb, 256u, sl.geom, A, kb, ke, m);
+        else
+            launch_k(sl, sfk::jacobi2k_kernel<T, NF, WL, NT, TJ, false>, nb, 256u, sl.geom, A, kb, ke, m);
+    }
+
+    template <int NF, bool NT>
+    void launch_march_k_tj(Slab& sl, const sfk::JacobiArgs<T, NF>& A, int kb, int ke, bool last) {
+        constexpr int WL = W / 2;  // 8 bytes per lane
+        switch (march_tj_) {
+            case 2: launch_march_k<NF, NT, 2, WL>(sl, A, kb, ke, last); break;
+            case 6: launch_march_k<NF, NT, 6, WL>(sl, A, kb, ke, last); break;
+            default: launch_march_k<NF, NT, 4, WL>(sl, A, kb, ke, last); break;
+        }
+    }
+
     template <int NF, bool SRC = false>
     void launch_jacobi2(Slab& sl, const sfk::JacobiArgs<T, NF>& A, int kb, int ke, bool first, bool last) {
         const bool nt = nt_mode_ == 1 ||
                         (nt_mode_ == 2 && (size_t)field_elems_ * sizeof(T) * 3 * NF > ((size_t)384 << 20));
+        if constexpr (!SRC) {
+            if (can_march_k(ke - kb, first)) {
+                if (nt)
+                    launch_march_k_tj<NF, true>(sl, A, kb, ke, last);
+                else
+                    launch_march_k_tj<NF, false>(sl, A, kb, ke, last);
+                return;
+            }
+        }
         if (can_march2() && !x_is_zero_ && !SRC) {  // implicit-zero / source pairs only exist in the register kernel
             if (nt)
                 launch_march2<NF, true>(sl, A, kb, ke, first, last);
@@ -1667,6 +1740,7 @@ private:
     int nzl_ = 0, lead_ = 0, px_ = 0, nplanes_ = 0, kchunk_ = 0, jacobi_mode_ = 2, tx_override_ = 0, nt_mode_ = 2, rb_shape_ = 0;
     bool ishell_skip_ = true, advect_lds_ = false, zero_skip_ = true, x_is_zero_ = false, fuse_src_ = true;
     int fuse2_ = 1, kc2_ = 32;
+    int march_k_ = 1, march_tj_ = 8, march_kc_ = 0, march_wg_per_cu_ = 1, march_min_planes_ = 12, march_ahead_ = 0;
     long plane_ = 0, field_elems_ = 0;
     std::vector<Slab> slabs_;
     ncclComm_t comm_ = nullptr;

@@ -931,6 +931,365 @@ __global__ void __launch_bounds__(256, SF_J2_WAVES) jacobi2_kernel(Geom g, Jacob
 #undef SF_DIST
 }
 
+// Register-resident k-marching form of the two-sweep kernel (2.5-D temporal blocking, wave-autonomous).
+//
+// Why: jacobi2_kernel recomputes the first sweep on a 12-position cross per 4 outputs (3x) and requests 36 vectors per
+// 4 outputs (9 x-loads per output): at 512^3 it moves 3.6 TB/s of real HBM traffic, bound by instruction issue and
+// the L1 / texture-address path at two waves per SIMD, not by HBM. Here a LANE owns one vector column and TJ
+// consecutive rows and marches along k: the j+-1 neighbours are the lane's own registers, the i+-1 neighbours come
+// from the adjacent lanes (DPP), the k+-1 neighbours are the planes it has just visited. Per output vector:
+// (TJ+4)/TJ loads of x, (TJ+2)/TJ of x0, (TJ+2)/TJ first-sweep evaluations (TJ = 8: 1.5 / 1.25 / 1.25 against
+// 9 / 3 / 3), no LDS, no barrier, no divergent loads. The register file (512 KB per CU) is the staging buffer: the
+// 160 KB LDS would hold fewer planes than the registers do, and nothing is shared between waves — each wave takes
+// SF_OVL_OUT consecutive (row group, vector) items of the plane in memory order in lanes SF_OVL_LO.., the outer lanes
+// only feed the shuffles (the overlapped mapping of jacobi2_kernel), so rows of any width fill the waves.
+//   plane kk of the march:  loads x(kk+2), x0(kk+1) go out first (one step ahead of their use);
+//                           y(kk)  = J(x)(kk) on rows j0-1 .. j0+TJ   from x(kk-1), x(kk), x(kk+1), x0(kk)
+//                           x''(kk-1) on rows j0 .. j0+TJ-1           from y(kk-2), y(kk-1), y(kk), x0(kk-1)
+// A chunk of KC output planes costs KC+2 first-sweep planes and KC+4 planes of x (the chunk ends), so chunks are
+// long (>= 16 planes) and there are just enough of them to fill the chip a whole number of times (launcher).
+// The first sweep's set_bnd is applied in registers exactly as in jacobi2_kernel: bit-identical results.
+// Handles the plain pairs of a lin_solve (x already swept once: i-shell recomputed, ishell_mem == 0); the first pair
+// (caller data on the i-shell, folded add_source, implicit zero) and the thin boundary launches of a decomposed grid
+// stay with jacobi2_kernel.
+struct MarchMap {
+    int ncol;          // waves per chunk (columns of SF_OVL_OUT items)
+    int band;          // workgroups per XCD band (grid = 8 x band x nchunks)
+    int kc;            // output planes per chunk
+    unsigned nvec_magic;
+    int nrg;           // row groups = ceil(N / TJ)
+};
+
+
+// Lane vector of the marching kernel: WL cells (8 bytes: two floats / one double by default — half the register state
+// per lane of the 16-byte vectors used elsewhere, which is what lets two waves share a SIMD; see jacobi2k_kernel).
+template <class T, int WL>
+struct LaneVec {
+    typedef T type __attribute__((ext_vector_type(WL)));
+};
+
+// Plane-relative addressing of the marching kernel: a buffer resource whose base is the (wave-uniform) start of one
+// plane plus a 32-bit per-lane byte offset (`buffer_load ... offen`): no 64-bit address arithmetic in vector registers.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t plane_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
+}
+template <class T, int WL>
+__device__ __forceinline__ typename LaneVec<T, WL>::type buf_load(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    typedef typename LaneVec<T, WL>::type VW;
+    constexpr int B = WL * (int)sizeof(T);
+    static_assert(B == 4 || B == 8 || B == 16, "lane vector must be 4, 8 or 16 bytes");
+    if constexpr (B == 4) {
+        return __builtin_bit_cast(VW, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+    } else if constexpr (B == 8) {
+        typedef int I2 __attribute__((ext_vector_type(2)));
+        return __builtin_bit_cast(VW, (I2)__builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0));
+    } else {
+        typedef int I4 __attribute__((ext_vector_type(4)));
+        return __builtin_bit_cast(VW, (I4)__builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+    }
+}
+template <class T, int WL, bool NT>
+__device__ __forceinline__ void buf_store(__amdgpu_buffer_rsrc_t r, unsigned off, typename LaneVec<T, WL>::type v) {
+    constexpr int B = WL * (int)sizeof(T);
+    constexpr int AUX = NT ? 2 : 0;  // nt
+    if constexpr (B == 4) {
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, off, 0, AUX);
+    } else if constexpr (B == 8) {
+        typedef int I2 __attribute__((ext_vector_type(2)));
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(I2, v), r, off, 0, AUX);
+    } else {
+        typedef int I4 __attribute__((ext_vector_type(4)));
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(I4, v), r, off, 0, AUX);
+    }
+}
+template <class T>
+__device__ __forceinline__ void buf_store1(__amdgpu_buffer_rsrc_t r, unsigned off, T v) {
+    if constexpr (sizeof(T) == 4) {
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, off, 0, 0);
+    } else {
+        typedef int I2 __attribute__((ext_vector_type(2)));
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(I2, v), r, off, 0, 0);
+    }
+}
+
+// set_bnd fused into the marching kernel: emit_shells with every address formed from a plane resource (wave-uniform)
+// and the byte offsets of rows j-1, j, j+1 the lane already holds — no address registers of its own. Same
+// expressions, same bits. `o` holds the WL interior cells at row j of plane ko; rm / rc / rp: planes ko-1, ko, ko+1.
+template <class T, int WL>
+__device__ __forceinline__ void j2k_shells(__amdgpu_buffer_rsrc_t rm, __amdgpu_buffer_rsrc_t rc,
+                                           __amdgpu_buffer_rsrc_t rp, unsigned offc, unsigned offm, unsigned offp,
+                                           typename LaneVec<T, WL>::type o, T sx, T sy, T sz, bool jlo, bool jhi,
+                                           bool klo, bool khi, bool ilo, bool ihi) {
+    typedef typename LaneVec<T, WL>::type VW;
+    constexpr unsigned LO = (unsigned)(-(int)sizeof(T)), HI = WL * (unsigned)sizeof(T);  // cells i = 0 / N+1
+    const T half = T(0.5);
+    const T third = (T)(1.0 / 3.0);
+    const T vlo = o[0], vhi = o[WL - 1];
+    if (ilo) buf_store1<T>(rc, offc + LO, sx * vlo);
+    if (ihi) buf_store1<T>(rc, offc + HI, sx * vhi);
+#pragma unroll
+    for (int sj = 0; sj < 2; ++sj) {
+        if (!(sj ? jhi : jlo)) continue;
+        const unsigned oj = sj ? offp : offm;
+        VW t;
+#pragma unroll
+        for (int e = 0; e < WL; ++e) t[e] = sy * o[e];
+        buf_store<T, WL, false>(rc, oj, t);
+        if (ilo) buf_store1<T>(rc, oj + LO, half * (sy * vlo + sx * vlo));
+        if (ihi) buf_store1<T>(rc, oj + HI, half * (sy * vhi + sx * vhi));
+    }
+#pragma unroll
+    for (int sk = 0; sk < 2; ++sk) {
+        if (!(sk ? khi : klo)) continue;
+        const __amdgpu_buffer_rsrc_t rk = sk ? rp : rm;
+        VW t;
+#pragma unroll
+        for (int e = 0; e < WL; ++e) t[e] = sz * o[e];
+        buf_store<T, WL, false>(rk, offc, t);
+        if (ilo) buf_store1<T>(rk, offc + LO, half * (sz * vlo + sx * vlo));
+        if (ihi) buf_store1<T>(rk, offc + HI, half * (sz * vhi + sx * vhi));
+#pragma unroll
+        for (int sj = 0; sj < 2; ++sj) {
+            if (!(sj ? jhi : jlo)) continue;
+            const unsigned oj = sj ? offp : offm;
+#pragma unroll
+            for (int e = 0; e < WL; ++e) t[e] = half * (sz * o[e] + sy * o[e]);
+            buf_store<T, WL, false>(rk, oj, t);
+#pragma unroll
+            for (int si = 0; si < 2; ++si) {
+                if (!(si ? ihi : ilo)) continue;
+                const T v = si ? vhi : vlo;
+                const T ex = half * (sz * v + sy * v);
+                const T ey = half * (sz * v + sx * v);
+                const T ez = half * (sy * v + sx * v);
+                buf_store1<T>(rk, oj + (si ? HI : LO), third * ((ex + ey) + ez));
+            }
+        }
+    }
+}
+
+// One plane of the march. The planes live in four-slot register rings (x: kk-1, kk, kk+1 and the plane in flight;
+// y: kk-2, kk-1, kk and a free slot; x0 likewise); PH = kk mod 4 is a compile-time constant in the four-fold
+// unrolled loop, so a "rotation" is a renaming and costs no instruction — and, more important, nothing has to wait
+// for the plane in flight before the step that consumes it.
+// The steady state must be free of branches around memory operations: hipcc merges its s_waitcnt bookkeeping at every
+// join by taking the stricter count, and a "stores issued / not issued" or "loads issued / not issued" join made
+// every step wait for its own stores to drain. Hence: the requests of step (1) are unconditional (the plane index is
+// clamped instead), OUT (whether this step has a second-sweep plane to produce: not in the first two steps of a
+// chunk) and WALLS / ISH (whether this wave ever touches a j / k wall; whether the i-shell is written) are template
+// parameters, and the loop is left by breaks, never re-joined.
+template <class T, int WL, bool NT, int TJ, int PH, bool OUT, bool WALLS, bool ISH>
+__device__ __forceinline__ void j2k_step(const Geom& g, typename LaneVec<T, WL>::type (&xr)[4][TJ + 4],
+                                         typename LaneVec<T, WL>::type (&yr)[4][TJ + 2],
+                                         typename LaneVec<T, WL>::type (&sr)[4][TJ + 2],
+                                         const unsigned (&rowb)[TJ + 4], const T* __restrict__ x,
+                                         const T* __restrict__ x0, T* __restrict__ xn, int kk, T a, T inv, T sx, T sy,
+                                         T sz, int j0, bool first_vec, bool last_vec, bool active) {
+    typedef typename LaneVec<T, WL>::type VW;
+    constexpr int RX = TJ + 4, RY = TJ + 2;
+    constexpr int XA = (PH + 0) & 3, XB = (PH + 1) & 3, XC = (PH + 2) & 3, XD = (PH + 3) & 3;
+    constexpr int YA = (PH + 0) & 3, YB = (PH + 1) & 3, YC = (PH + 2) & 3;
+    constexpr int SB = (PH + 0) & 3, SC = (PH + 1) & 3, SD = (PH + 2) & 3;
+    const int N = g.N;
+    const int kmax = g.np - 1;
+    // (1) requests for the next step: x(kk+2), x0(kk+1)
+    {
+        int kx = kk + 2, ks = kk + 1;
+        kx = kx > kmax ? kmax : kx;
+        ks = ks > kmax ? kmax : ks;
+        const __amdgpu_buffer_rsrc_t rd = plane_rsrc(x + (long)kx * g.plane);
+        const __amdgpu_buffer_rsrc_t rs = plane_rsrc(x0 + (long)ks * g.plane);
+#pragma unroll
+        for (int r = 0; r < RX; ++r) xr[XD][r] = buf_load<T, WL>(rd, rowb[r]);
+#pragma unroll
+        for (int r = 0; r < RY; ++r) sr[SD][r] = buf_load<T, WL>(rs, rowb[r + 1]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // (2) first sweep: y(kk) on rows j0-1 .. j0+TJ
+#pragma unroll
+    for (int r = 0; r < RY; ++r) {
+        const VW cc = xr[XB][r + 1];
+        const T up = lane_up(cc[WL - 1]);
+        const T dn = lane_dn(cc[0]);
+        const T xm = first_vec ? sx * cc[0] : up;
+        const T xp = last_vec ? sx * cc[WL - 1] : dn;
+        const VW jm = xr[XB][r], jp = xr[XB][r + 2], km = xr[XA][r + 1], kp = xr[XC][r + 1], s = sr[SC][r];
+        VW y;
+#pragma unroll
+        for (int e = 0; e < WL; ++e) {
+            const T left = (e == 0) ? xm : cc[e > 0 ? e - 1 : 0];
+            const T right = (e == WL - 1) ? xp : cc[e < WL - 1 ? e + 1 : WL - 1];
+            y[e] = (s[e] + a * (((left + right) + (jm[e] + jp[e])) + (km[e] + kp[e]))) * inv;
+        }
+        yr[YC][r] = y;
+    }
+    // (3) second sweep: x''(kk-1) on rows j0 .. j0+TJ-1
+    if constexpr (OUT) {
+        const int ko = kk - 1;
+        const int kg = g.kg0 + ko;
+        const bool klo = WALLS && g.wall_lo && kg == 1, khi = WALLS && g.wall_hi && kg == N;  // wave-uniform
+        T* __restrict__ po = xn + (long)ko * g.plane;
+        const __amdgpu_buffer_rsrc_t rc = plane_rsrc(po);
+#pragma unroll
+        for (int r = 0; r < TJ; ++r) {
+            const int j = j0 + r;
+            const VW yc = yr[YB][r + 1];
+            const T up = lane_up(yc[WL - 1]);
+            const T dn = lane_dn(yc[0]);
+            const T ym = first_vec ? sx * yc[0] : up;
+            const T yp = last_vec ? sx * yc[WL - 1] : dn;
+            VW jm = yr[YB][r], jp = yr[YB][r + 2], km = yr[YA][r + 1], kp = yr[YC][r + 1];
+            if constexpr (WALLS) {  // first-sweep set_bnd on the j / k walls
+                if (j == 1) jm = sy * yc;
+                if (j == N) jp = sy * yc;
+                if (klo) km = sz * yc;
+                if (khi) kp = sz * yc;
+            }
+            const VW s = sr[SB][r + 1];
+            VW o;
+#pragma unroll
+            for (int e = 0; e < WL; ++e) {
+                const T left = (e == 0) ? ym : yc[e > 0 ? e - 1 : 0];
+                const T right = (e == WL - 1) ? yp : yc[e < WL - 1 ? e + 1 : WL - 1];
+                o[e] = (s[e] + a * (((left + right) + (jm[e] + jp[e])) + (km[e] + kp[e]))) * inv;
+            }
+            if (active && j <= N) {
+                buf_store<T, WL, NT>(rc, rowb[r + 2], o);
+                if constexpr (WALLS)
+                    j2k_shells<T, WL>(plane_rsrc(po - g.plane), rc, plane_rsrc(po + g.plane), rowb[r + 2], rowb[r + 1],
+                                      rowb[r + 3], o, sx, sy, sz, j == 1, j == N, klo, khi, ISH && first_vec,
+                                      ISH && last_vec);
+                else if constexpr (ISH) {  // no wall near this wave: only the i = 0 / N+1 cells of the row
+                    if (first_vec) buf_store1<T>(rc, rowb[r + 2] - (unsigned)sizeof(T), sx * o[0]);
+                    if (last_vec) buf_store1<T>(rc, rowb[r + 2] + WL * (unsigned)sizeof(T), sx * o[WL - 1]);
+                }
+            }
+        }
+    }
+}
+
+template <class T, int WL, bool NT, int TJ, bool WALLS, bool ISH>
+__device__ __forceinline__ void j2k_march(const Geom& g, const unsigned (&rowb)[TJ + 4], const T* __restrict__ x,
+                                          const T* __restrict__ x0, T* __restrict__ xn, int k0, int k1, T a, T inv,
+                                          T sx, T sy, T sz, int j0, bool first_vec, bool last_vec, bool active) {
+    typedef typename LaneVec<T, WL>::type VW;
+    constexpr int RX = TJ + 4, RY = TJ + 2;
+    const int kmax = g.np - 1;
+    auto plane_of_k = [&](const T* base, int kl) -> __amdgpu_buffer_rsrc_t {
+        kl = kl < 0 ? 0 : (kl > kmax ? kmax : kl);
+        return plane_rsrc(base + (long)kl * g.plane);
+    };
+    // rings, phase 0 at kk = k0-1: x slots (A,B,C,D) = (0,1,2,3); y (A,B,C) = (0,1,2); x0 (B,C,D) = (0,1,2)
+    VW xr[4][RX], yr[4][RY], sr[4][RY];
+    {
+        const __amdgpu_buffer_rsrc_t pa = plane_of_k(x, k0 - 2), pb = plane_of_k(x, k0 - 1), pc = plane_of_k(x, k0);
+        const __amdgpu_buffer_rsrc_t ps = plane_of_k(x0, k0 - 1);
+#pragma unroll
+        for (int r = 0; r < RX; ++r) {
+            xr[0][r] = buf_load<T, WL>(pa, rowb[r]);
+            xr[1][r] = buf_load<T, WL>(pb, rowb[r]);
+            xr[2][r] = buf_load<T, WL>(pc, rowb[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < RY; ++r) sr[1][r] = buf_load<T, WL>(ps, rowb[r + 1]);
+    }
+#define SF_J2K_STEP(PH_, OUT_)                                                                                     \
+    j2k_step<T, WL, NT, TJ, PH_, OUT_, WALLS, ISH>(g, xr, yr, sr, rowb, x, x0, xn, kk, a, inv, sx, sy, sz, j0,      \
+                                                   first_vec, last_vec, active)
+    int kk = k0 - 1;
+    SF_J2K_STEP(0, false);  // y(k0-1)
+    ++kk;
+    SF_J2K_STEP(1, false);  // y(k0)
+    ++kk;
+    for (;;) {  // kk = k0+1 .. k1: y(kk) and x''(kk-1); a chunk has at least one plane, so k0+1 <= k1
+        SF_J2K_STEP(2, true);
+        if (++kk > k1) break;
+        SF_J2K_STEP(3, true);
+        if (++kk > k1) break;
+        SF_J2K_STEP(0, true);
+        if (++kk > k1) break;
+        SF_J2K_STEP(1, true);
+        if (++kk > k1) break;
+    }
+#undef SF_J2K_STEP
+}
+
+#ifndef SF_J2K_WAVES
+#define SF_J2K_WAVES 2
+#endif
+
+template <class T, int NF, int WL, bool NT, int TJ, bool ISH>
+__global__ void __launch_bounds__(256, SF_J2K_WAVES) jacobi2k_kernel(Geom g, JacobiArgs<T, NF> A, int kb, int ke,
+                                                                     MarchMap m) {
+    constexpr int RX = TJ + 4;  // rows of x held per plane: j0-2 .. j0+TJ+1 (y: j0-1 .. j0+TJ)
+    const int N = g.N;
+    const int nvec = N / WL;
+    const int cb = (int)blockIdx.x * m.band + (int)blockIdx.y;  // column block; workgroup x runs on XCD group x
+    int chunk, f;
+    {
+        const int nchunk = (ke - kb + m.kc - 1) / m.kc;
+        if (NF == 1) {
+            chunk = (int)blockIdx.z;
+            f = 0;
+        } else {
+            chunk = (int)blockIdx.z % nchunk;
+            f = (int)blockIdx.z / nchunk;
+        }
+    }
+    const int tid = (int)threadIdx.x;
+    const int lane = tid & 63;
+    const int col = cb * 4 + (tid >> 6);
+    if (col >= m.ncol) return;  // whole waves; nothing in this kernel crosses waves
+    const int total = m.nrg * nvec;
+    int t = col * SF_OVL_OUT + lane - SF_OVL_LO;
+    const bool active = t >= 0 && t < total && lane >= SF_OVL_LO && lane < SF_OVL_LO + SF_OVL_OUT;
+    t = t < 0 ? 0 : (t >= total ? total - 1 : t);  // feeder / padding lanes run on valid addresses
+    const int rg = nvec == 1 ? t : (int)__umulhi((unsigned)t, m.nvec_magic);
+    const int vec = t - rg * nvec;
+    const int j0 = 1 + rg * TJ;
+    const int i0 = 1 + WL * vec;
+    const int k0 = kb + chunk * m.kc;
+    const int k1 = (k0 + m.kc < ke) ? k0 + m.kc : ke;
+
+    const T a = A.a, inv = A.inv;
+    const T* __restrict__ x = A.x[0];
+    const T* __restrict__ x0 = A.x0[0];
+    T* __restrict__ xn = A.xn[0];
+    int b = A.b[0];
+#pragma unroll
+    for (int ff = 1; ff < NF; ++ff)
+        if (f == ff) {
+            x = A.x[ff];
+            x0 = A.x0[ff];
+            xn = A.xn[ff];
+            b = A.b[ff];
+        }
+    const T sx = (b == 1) ? T(-1) : T(1);
+    const T sy = (b == 2) ? T(-1) : T(1);
+    const T sz = (b == 3) ? T(-1) : T(1);
+
+    // per-lane BYTE offsets of the rows inside a plane (32 bit: a plane is far below 2 GiB)
+    unsigned rowb[RX];
+#pragma unroll
+    for (int r = 0; r < RX; ++r) {
+        int j = j0 - 2 + r;
+        j = j < 0 ? 0 : (j > N + 1 ? N + 1 : j);
+        rowb[r] = (unsigned)(j * g.px + (g.lead - 1) + i0) * (unsigned)sizeof(T);
+    }
+    const bool first_vec = (vec == 0), last_vec = (vec == nvec - 1);
+    // does this wave ever touch a j wall (fixed per lane for the whole march) or a k wall (first / last plane of a
+    // wall slab inside this chunk)? Most waves do not and take the instantiation without any wall code
+    const bool lane_jwall = (j0 <= 1) | (j0 + TJ - 1 >= N);
+    const bool kwall = (g.wall_lo && g.kg0 + k0 <= 1) | (g.wall_hi && g.kg0 + k1 - 1 >= N);
+    const bool wave_walls = kwall | (__builtin_amdgcn_ballot_w64(lane_jwall) != 0ull);
+    if (wave_walls)
+        j2k_march<T, WL, NT, TJ, true, ISH>(g, rowb, x, x0, xn, k0, k1, a, inv, sx, sy, sz, j0, first_vec, last_vec,
+                                            active);
+    else
+        j2k_march<T, WL, NT, TJ, false, ISH>(g, rowb, x, x0, xn, k0, k1, a, inv, sx, sy, sz, j0, first_vec, last_vec,
+                                             active);
+}
+
 // LDS-staged, k-marching form of the two-sweep kernel (2.5-D temporal blocking).
 // A workgroup of NV x 4 threads (NV = vectors per row rounded up to 64) owns TJ output rows of full
 // width and marches `kchunk` planes. Per step it (1) publishes the x rows of plane k+1 (TJ+4 rows,
