@@ -7,14 +7,22 @@
 
 One "step" = vel_step + dens_step with the resident sources re-injected (sf_bind_sources) over the whole
 grid (BASELINE.json metric: Mcells/s per vel_step+dens_step, 20 Jacobi iterations). At N = 1 the
-workload is BASELINE.json configs[1]: 256^3 fp32, K = 20. For N > 1 the grid is slab-decomposed along
-k, one slab per GPU, with RCCL halo exchange; the per-GPU cell count is kept at ~256^3 (weak scaling:
-N_g = 324 / 408 / 512 for 2 / 4 / 8 GPUs). Inputs are the analytic fields of docs/SPEC.md §5, resident
-in HBM before the timed region starts.
+workload is BASELINE.json configs[1]: 256^3 fp32, K = 20. For N > 1 the workload is configs[3]: the
+1024^3 fp32 grid, slab-decomposed along k, one slab per GPU, RCCL halo exchange ("scaling": "strong" —
+the grid is the same for every N; north_star's target is >= 6x at 8 GPUs on it). After the distributed
+phase rank 0 times the SAME grid on its own GPU alone for a few steps, so the line carries an in-run
+one-GPU denominator (`single_gpu`) and `speedup`. `--weak` keeps ~256^3 cells per GPU instead
+(N_g = 320 / 408 / 512 for 2 / 4 / 8 GPUs, "scaling": "weak"). Inputs are the analytic fields of
+docs/SPEC.md §5, resident in HBM before the timed region starts.
 
 Rank 0 prints ONE JSON line. Besides the contract fields it carries
-  roofline     : the Jacobi lin_solve sweep (dominant kernel) timed with HIP events on its own stream
-  cpu_baseline : the serial CPU oracle (oracle/, "port") on the same workload, bounded sample
+  roofline                : the dominant kernel (fused Jacobi sweeps of lin_solve) at 512^3 — the working set is far
+                            beyond the 256 MiB Infinity Cache, so `achieved` is a statement about HBM — timed with
+                            HIP events on the launch stream; `traffic` = counter-measured bytes per launch with its
+                            provenance (a committed PMC pass: bench.py cannot run rocprofv3 on itself)
+  roofline_cache_resident : the same kernel on the benchmark grid (256^3: x, x0, x' of one field fit the Infinity
+                            Cache, so the algorithmic rate can exceed the HBM peak — not an HBM measurement)
+  cpu_baseline            : the serial CPU oracle (oracle/, "port") on the same workload, bounded sample
 The oracle is only the baseline/checker here, never the thing measured as `value`.
 """
 import argparse
@@ -30,7 +38,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured float4 copy)
-WEAK_GRID = {1: 256, 2: 320, 4: 408, 8: 512}  # N_g^3 / gpus ~= 256^3, N_g divisible by gpus and by 4
+WEAK_GRID = {1: 256, 2: 320, 4: 408, 8: 512}  # --weak: N_g^3 / gpus ~= 256^3, N_g divisible by gpus and by 4
+STRONG_GRID = 1024  # BASELINE.json configs[3]: the grid of every N > 1 run
 
 
 def parse():
@@ -38,7 +47,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--grid", dest="n", type=int, default=0, help="grid size override (default: 256 per GPU, weak scaling)")
+    ap.add_argument("--grid", dest="n", type=int, default=0,
+                    help="grid size override (default: 256 at N = 1, 1024 for N > 1)")
+    ap.add_argument("--weak", action="store_true", help="N > 1: ~256^3 cells per GPU instead of the 1024^3 grid")
+    ap.add_argument("--single-steps", type=int, default=3,
+                    help="N > 1: steps of the same grid timed on rank 0's GPU alone afterwards (0 = skip)")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--roofline-n", type=int, default=512, help="also time the lin_solve sweep at this size")
@@ -80,14 +93,31 @@ def analytic_planes(N, kb, ke, dt, dtype):
     return out
 
 
+def upload_inputs(fs, N, dt, batch=32):
+    """Analytic inputs for the planes this context stores, generated and uploaded `batch` planes at a time (the
+    1024^3 fields are 4.3 GB each: never materialised whole on the host), then the shells."""
+    kb, ke = fs.stored_planes()
+    for b0 in range(kb, ke, batch):
+        b1 = min(b0 + batch, ke)
+        f = analytic_planes(N, b0, b1, dt, fs.np_dtype)
+        for name, slot in (("u", "u"), ("v", "v"), ("w", "w"), ("dens", "dens"), ("su", "user0"), ("sv", "user1"),
+                           ("sw", "user2"), ("sd", "user3")):
+            fs.upload_planes(slot, b0, f[name])
+    for b, n in ((1, "u"), (2, "v"), (3, "w"), (0, "dens")):
+        fs.set_bnd(b, n)
+    fs.sync()
+
+
 def words_per_cell_step(K):
     return 56 + 18 * K  # SURVEY.md §8a/§8d: dens_step 8+3K, vel_step 48+15K
 
 
 def time_lin_solve(S, N, dtype, K, reps, device):
-    """Average duration of ONE Jacobi kernel launch at size N (NF = 1), HIP events on the context's compute
-    stream around lin_solve(K), divided by the number of launches it issues (sweeps are fused in pairs where
-    the layout allows: sf_lin_solve_launches). Returns (mean us/launch, min us/launch, sweeps per launch)."""
+    """Duration of the Jacobi launches of lin_solve at size N (NF = 1), HIP events on the context's compute stream.
+    A K-sweep solve is one first launch of two fused sweeps (its iterate is caller data: the pair kernel that reads
+    the i-shell from memory) followed by launches of the dominant kernel, which fuses up to three sweeps
+    (sf_lin_solve_launches tells how many launches a solve issues). Timed: lin_solve(K) and lin_solve(2); the dominant
+    kernel's launches are the difference. Returns a dict (all times in microseconds)."""
     with S.FluidSolver(N, dtype=dtype, iters=K, device=device) as fs:
         rng = np.random.RandomState(1)
         plane = rng.standard_normal((1, N + 2, N + 2)).astype(fs.np_dtype)
@@ -96,15 +126,24 @@ def time_lin_solve(S, N, dtype, K, reps, device):
             fs.upload_planes("dens0", k, plane * (0.5 - 0.001 * k))
         a, c = 0.3, 1 + 6 * 0.3
         launches = fs.lin_solve_launches(K)
-        fs.lin_solve(0, "dens", "dens0", a, c, 2)  # warm-up
+        first = fs.lin_solve_launches(2)  # 1 where sweep pairs are fused
+        fs.lin_solve(0, "dens", "dens0", a, c, K)  # warm-up
         fs.sync()
-        per = []
+        tk, t2 = [], []
         for _ in range(reps):
             fs.timer_start()
             fs.lin_solve(0, "dens", "dens0", a, c, K)
-            per.append(fs.timer_stop() * 1e3 / launches)
+            tk.append(fs.timer_stop() * 1e3)
+            fs.timer_start()
+            fs.lin_solve(0, "dens", "dens0", a, c, 2)
+            t2.append(fs.timer_stop() * 1e3)
         fs.sync()
-        return float(np.mean(per)), float(np.min(per)), K / launches
+        rest = launches - first
+        dom = [(x - y) / rest for x, y in zip(tk, t2)] if rest > 0 else [x / launches for x in tk]
+        return {"us_per_launch": float(np.mean(dom)), "us_per_launch_min": float(np.min(dom)),
+                "sweeps_per_launch": (K - 2) / rest if rest > 0 else K / launches,
+                "us_first_launch": float(np.mean(t2)) / max(first, 1), "launches_per_solve": launches,
+                "us_per_sweep_whole_solve": float(np.mean(tk)) / K}
 
 
 def cpu_baseline(N, K, dtype, steps, dt, diff, visc):
@@ -167,8 +206,15 @@ def main():
         from fluidsolvergpu_amd import solver as S
 
     K, dt, diff, visc = args.iters, 0.1, 1e-4, 1e-4
-    N = args.n if args.n > 0 else WEAK_GRID.get(world, 256 * world)
+    if args.n > 0:
+        N = args.n
+    elif world == 1:
+        N = 256
+    else:
+        N = WEAK_GRID.get(world, 256 * world) if args.weak else STRONG_GRID
     assert N % world == 0, f"grid {N} not divisible by {world} ranks"
+    # per-GPU work shrinks with N when the grid is fixed (strong), stays put with --weak
+    scaling = "weak" if (world == 1 or args.weak) else "strong"
     nccl_id = sfdist.share_nccl_id(dist, S.nccl_unique_id)
     # SF_BENCH_LOOPBACK=1 (with SF_FORCE_DEVICE=0): rehearsal of this file's multi-process path on a one-GPU box, where
     # RCCL refuses two ranks on one device — every rank runs its own slab with SF_FLAG_LOOPBACK_HALO (halo messages
@@ -177,15 +223,7 @@ def main():
     kw = {"flags": 1} if loopback else {}
     fs = S.FluidSolver(N, dtype=args.dtype, iters=K, dt=dt, diff=diff, visc=visc, device=local_rank, rank=rank,
                        nranks=world, nccl_id=None if loopback else nccl_id, nslabs_local=args.local_slabs, **kw)
-    kb, ke = fs.stored_planes()
-    f = analytic_planes(N, kb, ke, dt, fs.np_dtype)
-    for name, slot in (("u", "u"), ("v", "v"), ("w", "w"), ("dens", "dens"), ("su", "user0"), ("sv", "user1"),
-                       ("sw", "user2"), ("sd", "user3")):
-        fs.upload_planes(slot, kb, f[name])
-    for b, n in ((1, "u"), (2, "v"), (3, "w"), (0, "dens")):
-        fs.set_bnd(b, n)
-    fs.sync()
-    del f
+    upload_inputs(fs, N, dt)
 
     # per-step source re-injection: the sources stay resident in SF_USER0..3 and are bound, which is bit-identical
     # to copying them into u0/v0/w0/dens0 before every step (tests/test_parity_gpu.py::test_bound_sources)
@@ -234,7 +272,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": args.dtype,
             "data": ("DRYRUN - no computation" if os.environ.get("SF_BENCH_DRYRUN") == "1"
@@ -248,32 +286,82 @@ def main():
             "achieved_hbm_gbps_step": step_bytes / (elapsed / args.steps) / 1e9 / world,
             "step_algorithmic_bytes_per_cell": words_per_cell_step(K) * wsize,
             "hbm_copy_gbps_same_run": copy_gbps,
+            "transport": fs.transport_info() if hasattr(fs, "transport_info") else None,
         }
     fs.close()
 
+    # ---- N > 1: the same grid on ONE GPU (rank 0's), in the same run: the denominator of `speedup` ----
+    if world > 1 and args.single_steps > 0 and not loopback:
+        if dist is not None:
+            dist.barrier()  # every rank has released its slab
+        if rank == 0:
+            try:
+                with S.FluidSolver(N, dtype=args.dtype, iters=K, dt=dt, diff=diff, visc=visc, device=local_rank) as f1:
+                    upload_inputs(f1, N, dt)
+                    f1.bind_sources("user0", "user1", "user2", "user3")
+                    f1.vel_step()
+                    f1.dens_step()
+                    f1.sync()
+                    t0 = time.perf_counter()
+                    for _ in range(args.single_steps):
+                        f1.vel_step()
+                        f1.dens_step()
+                    f1.sync()
+                    t1 = (time.perf_counter() - t0) / args.single_steps
+                out["single_gpu"] = {"grid": N, "steps": args.single_steps, "ms_per_step": t1 * 1e3,
+                                     "value": float(N) ** 3 / t1 / 1e6, "unit": "Mcells/s",
+                                     "note": "same grid, same inputs, rank 0's GPU alone, timed after the distributed phase"}
+                out["speedup"] = out["value"] / out["single_gpu"]["value"]
+            except Exception as exc:  # e.g. the grid does not fit one GPU: report, do not fail the run
+                out["single_gpu"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+                out["speedup"] = None
+
     if rank == 0:
-        # ---- roofline leg: the Jacobi sweep, per launch, HIP events on the launch stream -------
-        n_local = N if world == 1 else WEAK_GRID[1]
+        # ---- roofline leg: the dominant kernel, per launch, HIP events on the launch stream -------
         wsize = 4 if args.dtype == "f32" else 8
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        def roofline_entry(n):
-            us, us_min, spl = time_lin_solve(S, n, args.dtype, K, 5 if n <= 256 else 3, local_rank)
-            alg = float(n) ** 3 * 3 * wsize * spl  # 3 words per cell per sweep x sweeps per launch
-            tr = traffic.get(f"jacobi_nf1_{args.dtype}_{n}")
-            return {"bound": "hbm", "kernel": "jacobi2_kernel<T,1,*,2,2>: two fused lin_solve sweeps + set_bnd per launch"
-                    if spl == 2 else "jacobi_rb_kernel<T,1,*>: one lin_solve sweep + set_bnd per launch",
-                    "achieved": alg / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, "traffic": tr, "grid": n,
-                    "us_per_launch": us, "us_per_launch_min": us_min, "sweeps_per_launch": spl,
-                    "algorithmic_bytes_per_launch": alg}
-
         traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}
-        out["roofline"] = roofline_entry(n_local)
-        out["roofline"]["note"] = ("algorithmic bytes = 3 words/cell/sweep x sweeps per launch; fusing two sweeps halves "
-                                   "the HBM traffic per sweep (see traffic), and the 256^3 working set (~240 MB) sits "
-                                   "largely in the 256 MiB Infinity Cache — roofline_hbm is the 512^3 figure")
-        if args.roofline_n and args.roofline_n != n_local:
-            out["roofline_hbm"] = roofline_entry(args.roofline_n)
+
+        def roofline_entry(n):
+            r = time_lin_solve(S, n, args.dtype, K, 5 if n <= 256 else 3, local_rank)
+            spl = r["sweeps_per_launch"]
+            alg = float(n) ** 3 * 3 * wsize * spl  # SURVEY.md §8d: 3 words per cell per sweep x sweeps per launch
+            us = max(r["us_per_launch"], 1e-9)
+            tr = traffic.get(f"jacobi_{args.dtype}_{n}")
+            e = {"bound": "hbm",
+                 "kernel": ("jacobi_sk_kernel<T,1,*,S=3>: three fused lin_solve sweeps + set_bnd per launch (k-marching, LDS "
+                            "halo exchange)" if spl > 2.5 else
+                            "two fused lin_solve sweeps + set_bnd per launch" if spl > 1.5 else
+                            "jacobi_rb_kernel<T,1,*>: one lin_solve sweep + set_bnd per launch"),
+                 "achieved": alg / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                 "frac": alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, "grid": n, "us_per_launch": us,
+                 "us_per_launch_min": r["us_per_launch_min"], "sweeps_per_launch": spl,
+                 "algorithmic_bytes_per_launch": alg, "us_first_launch_of_a_solve": r["us_first_launch"],
+                 "launches_per_solve": r["launches_per_solve"], "us_per_sweep_whole_solve": r["us_per_sweep_whole_solve"]}
+            if tr:
+                e["traffic"] = tr["bytes_per_launch"]
+                e["frac_traffic"] = tr["bytes_per_launch"] / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS
+                e["traffic_provenance"] = {"file": "profiles/traffic_latest.json", "tag": tr.get("tag"),
+                                           "source": tr.get("source"), "kernel": tr.get("kernel"),
+                                           "note": "FETCH_SIZE x2 + WRITE_SIZE from separate rocprofv3 --pmc passes of an "
+                                                   "earlier run of the same kernel; not measured in this run"}
+            else:
+                e["traffic"] = None
+            return e
+
+        hbm_n = args.roofline_n if args.roofline_n else 512
+        out["roofline"] = roofline_entry(hbm_n)
+        out["roofline"]["note"] = (f"{hbm_n}^3: x, x0 and x' of the solve (3 x {float(hbm_n) ** 3 * wsize / 1e6:.0f} MB) are far "
+                                   "beyond the 256 MiB Infinity Cache, so this is an HBM measurement. algorithmic bytes = 3 "
+                                   "words/cell/sweep x sweeps per launch: fusing S sweeps into one pass divides the real HBM "
+                                   "traffic per sweep by S, which is why `achieved` can exceed the peak while `frac_traffic` "
+                                   "(counter bytes / time / peak) cannot")
+        n_bench = N if world == 1 else WEAK_GRID[1]
+        if n_bench != hbm_n:
+            out["roofline_cache_resident"] = roofline_entry(n_bench)
+            out["roofline_cache_resident"]["note"] = (
+                f"{n_bench}^3: the solve's working set sits largely in the 256 MiB Infinity Cache, so `frac` is NOT a "
+                "fraction of HBM bandwidth and may exceed 1")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(N, K, args.dtype, args.cpu_steps, dt, diff, visc)
         print(json.dumps(out), flush=True)

@@ -266,12 +266,12 @@ public:
         trap_m_ = env_int("SF_TRAP", (nranks_ > 1 || rccl_self_) ? 0 : 5);  // pairs per trapezoid block of a decomposed lin_solve (<= 1: off)
         strip_mode_ = env_int("SF_STRIP", 0);  // 0 heuristic, 1 dense, 2 wave-aligned row strips in the fused kernel
         graphs_ = env_int("SF_GRAPH", 0) != 0 && P_ == 1;
-        march_k_ = env_int("SF_MARCH", 1);
-        march_tj_ = env_int("SF_MARCH_TJ", 6);
-        march_kc_ = env_int("SF_MARCH_KC", 0);
-        march_wg_per_cu_ = env_int("SF_MARCH_WGCU", 0);  // workgroups per CU assumed by the chunk heuristic (0: by TJ)
+        march_k_ = env_int("SF_MARCH", 1);  // 0: the register-blocked pair kernel everywhere
         march_min_planes_ = env_int("SF_MARCH_MINP", 12);
-        march_ahead_ = env_int("SF_MARCH_AHEAD", 0);
+        sk_s_ = env_int("SF_SK_S", 3);
+        sk_cfg_ = env_int("SF_SK_CFG", 0);
+        sk_kc_ = env_int("SF_SK_KC", 0);
+        sk_wgcu_ = env_int("SF_SK_WGCU", 0);
         SF_HIP(hipDeviceSynchronize());
         if ((nranks_ > 1 || rccl_self_) && std::getenv("SF_TRAP") == nullptr && env_int("SF_AUTOTUNE", 1)) tune_schedule();
     }
@@ -860,7 +860,11 @@ public:
         SF_HIP(hipStreamSynchronize(sl.cs));
     }
 
-    int lin_solve_launches(int iters) const override { return can_fuse2() ? iters / 2 + iters % 2 : iters; }
+    int lin_solve_launches(int iters) const override {
+        int n = 0;
+        for (int it = 0; it < iters; ++n) it += sweeps_in_launch(it, iters, false);
+        return n;
+    }
 
     void schedule_info(int* trap, int* measured) const override {
         if (trap) *trap = trap_m_ > 1 ? trap_m_ : 0;
@@ -1409,39 +1413,43 @@ private:
                            sl.geom, A, kb, ke, m, kc);
     }
 
-    // Register-resident k-marching pair kernel (sfk::jacobi2k_kernel): the plain pairs of a solve on plane ranges
-    // long enough to march. SF_MARCH=0 switches it off; SF_MARCH_TJ (2, 4, 8) rows per lane; SF_MARCH_KC planes per chunk.
+    // k-marching S-sweep kernel (sfk::jacobi_sk_kernel): the plain passes of a solve (iterate already swept once, so its
+    // i-shell is recomputed in registers) on plane ranges long enough to march. SF_MARCH=0 switches it off.
     bool can_march_k(int nplanes, bool first) const {
         return march_k_ != 0 && !first && ishell_skip_ && split_ == INT_MAX && nplanes >= march_min_planes_ && !x_is_zero_;
     }
 
-    template <int NF, bool NT, int TJ, int WL>
-    void launch_march_k(Slab& sl, const sfk::JacobiArgs<T, NF>& A, int kb, int ke, bool last) {
+    // S fused sweeps with LDS halo exchange (sfk::jacobi_sk_kernel). Same eligibility as the two-sweep marching kernel;
+    // three sweeps only on an undecomposed grid (a slab boundary would need three ghost planes).
+    bool can_sk(int nplanes, bool first) const { return can_march_k(nplanes, first); }
+    int sk_max_sweeps() const { return (march_k_ != 0 && P_ == 1) ? std::min(sk_s_, 3) : 2; }
+
+    template <bool NT, int S, int TJ, int NW>
+    void launch_sk_cfg(Slab& sl, const sfk::JacobiArgs<T, 1>& A, int kb, int ke, bool last) {
+        constexpr int WL = W / 2;  // 8 bytes per lane
+        constexpr int V = NW * TJ - 2 * S, P = 64 - 2 * S;
         const int nvec = N_ / WL;
-        sfk::MarchMap m{};
-        m.nrg = ceil_div(N_, TJ);
-        const long items = (long)m.nrg * nvec;
-        m.ncol = (int)ceil_div(items, (long)sfk::SF_OVL_OUT);
-        const int wgs = ceil_div(m.ncol, 4);
-        m.band = ceil_div(wgs, 8);
+        sfk::SkMap m{};
+        m.njb = ceil_div(N_, V);
+        const long items = (long)m.njb * nvec;
+        m.ncb = (int)ceil_div(items, (long)P);
+        m.band = ceil_div(m.ncb, 8);
         m.nvec_magic = nvec > 1 ? 0xFFFFFFFFu / (unsigned)nvec + 1u : 0u;
         const int np = ke - kb;
-        // chunks: as long as possible (a chunk pays 2 extra first-sweep planes and 4 extra planes of x), but enough
-        // workgroups to fill the chip a whole number of times
         int nchunk;
-        if (march_kc_ > 0 || np >= 64) {
-            // measured (512^3, 256^3 fp32): 32-plane chunks beat the "fill the chip a whole number of times" choice
-            nchunk = ceil_div(np, march_kc_ > 0 ? march_kc_ : 32);
+        if (sk_kc_ > 0) {
+            nchunk = ceil_div(np, sk_kc_);
         } else {
-            const long cap = (long)num_cu_ * (march_wg_per_cu_ > 0 ? march_wg_per_cu_ : (TJ <= 2 ? 4 : 2));
+            // a chunk costs 2S-2 extra steps: as few chunks as fill the chip a whole number of times
+            const long cap = (long)num_cu_ * (sk_wgcu_ > 0 ? sk_wgcu_ : (NW == 8 ? 1 : 2));
             const int max_chunks = std::max(1, np / 8);
             double best = -1;
             nchunk = 1;
             for (int c = 1; c <= max_chunks; ++c) {
                 const int kc = ceil_div(np, c);
-                const long total = (long)wgs * NF * ceil_div(np, kc);
+                const long total = (long)m.ncb * ceil_div(np, kc);
                 const long rounds = ceil_div(total, cap);
-                const double tm = (double)rounds * (kc + 4);  // time ~ rounds x (kc + 4) steps; prefer the shortest
+                const double tm = (double)rounds * (kc + 2 * S - 2 + 3);
                 if (best < 0 || tm < best * 0.999) {
                     best = tm;
                     nchunk = c;
@@ -1450,21 +1458,64 @@ private:
         }
         m.kc = ceil_div(np, nchunk);
         nchunk = ceil_div(np, m.kc);
-        const dim3 nb(8u, (unsigned)m.band, (unsigned)(nchunk * NF));
-        if (last)  // the last sweep of the solve writes the i = 0 / N+1 shell cells
-            launch_k(sl, sfk::jacobi2k_kernel<T, NF, WL, NT, TJ, true>, nb, 256u, sl.geom, A, kb, ke, m);
+        const dim3 nb(8u, (unsigned)m.band, (unsigned)nchunk);
+        if (last)
+            launch_k(sl, sfk::jacobi_sk_kernel<T, 1, WL, NT, S, TJ, NW, true>, nb, 64u * NW, sl.geom, A, kb, ke, m);
         else
-            launch_k(sl, sfk::jacobi2k_kernel<T, NF, WL, NT, TJ, false>, nb, 256u, sl.geom, A, kb, ke, m);
+            launch_k(sl, sfk::jacobi_sk_kernel<T, 1, WL, NT, S, TJ, NW, false>, nb, 64u * NW, sl.geom, A, kb, ke, m);
     }
 
-    template <int NF, bool NT>
-    void launch_march_k_tj(Slab& sl, const sfk::JacobiArgs<T, NF>& A, int kb, int ke, bool last) {
-        constexpr int WL = W / 2;  // 8 bytes per lane
-        switch (march_tj_) {
-            case 2: launch_march_k<NF, NT, 2, WL>(sl, A, kb, ke, last); break;
-            case 6: launch_march_k<NF, NT, 6, WL>(sl, A, kb, ke, last); break;
-            default: launch_march_k<NF, NT, 4, WL>(sl, A, kb, ke, last); break;
+    template <int NF, int S>
+    void launch_sk(Slab& sl, const sfk::JacobiArgs<T, NF>& A, int kb, int ke, bool last) {
+        const bool nt = nt_mode_ == 1 ||
+                        (nt_mode_ == 2 && (size_t)field_elems_ * sizeof(T) * 3 * NF > ((size_t)384 << 20));
+        for (int f = 0; f < NF; ++f) {  // one launch per field (fields are independent)
+            sfk::JacobiArgs<T, 1> B;
+            B.x[0] = A.x[f];
+            B.x0[0] = A.x0[f];
+            B.xn[0] = A.xn[f];
+            B.b[0] = A.b[f];
+            B.a = A.a;
+            B.inv = A.inv;
+#ifndef SF_SK_CFGS
+#define SF_SK_CFGS 1  // bit q: instantiate configuration q (0: 6 rows x 8 waves, 1: 4 x 4, 2: 6 x 4, 3: 4 x 8)
+#endif
+            const int cfg = ((SF_SK_CFGS >> sk_cfg_) & 1) ? sk_cfg_ : __builtin_ctz(SF_SK_CFGS);
+            if ((SF_SK_CFGS & 2) && cfg == 1) {
+                if constexpr ((SF_SK_CFGS & 2) != 0) {
+                    if (nt)
+                        launch_sk_cfg<true, S, 4, 4>(sl, B, kb, ke, last);
+                    else
+                        launch_sk_cfg<false, S, 4, 4>(sl, B, kb, ke, last);
+                }
+            } else if ((SF_SK_CFGS & 4) && cfg == 2) {
+                if constexpr ((SF_SK_CFGS & 4) != 0) {
+                    if (nt)
+                        launch_sk_cfg<true, S, 6, 4>(sl, B, kb, ke, last);
+                    else
+                        launch_sk_cfg<false, S, 6, 4>(sl, B, kb, ke, last);
+                }
+            } else if ((SF_SK_CFGS & 8) && cfg == 3) {
+                if constexpr ((SF_SK_CFGS & 8) != 0) {
+                    if (nt)
+                        launch_sk_cfg<true, S, 4, 8>(sl, B, kb, ke, last);
+                    else
+                        launch_sk_cfg<false, S, 4, 8>(sl, B, kb, ke, last);
+                }
+            } else {
+                if constexpr ((SF_SK_CFGS & 1) != 0) {
+                    if (nt)
+                        launch_sk_cfg<true, S, 6, 8>(sl, B, kb, ke, last);
+                    else
+                        launch_sk_cfg<false, S, 6, 8>(sl, B, kb, ke, last);
+                }
+            }
         }
+    }
+
+    template <int NF>
+    void launch_jacobi3(Slab& sl, const sfk::JacobiArgs<T, NF>& A, int kb, int ke, bool last) {
+        launch_sk<NF, 3>(sl, A, kb, ke, last);
     }
 
     template <int NF, bool SRC = false>
@@ -1472,11 +1523,8 @@ private:
         const bool nt = nt_mode_ == 1 ||
                         (nt_mode_ == 2 && (size_t)field_elems_ * sizeof(T) * 3 * NF > ((size_t)384 << 20));
         if constexpr (!SRC) {
-            if (can_march_k(ke - kb, first)) {
-                if (nt)
-                    launch_march_k_tj<NF, true>(sl, A, kb, ke, last);
-                else
-                    launch_march_k_tj<NF, false>(sl, A, kb, ke, last);
+            if (can_sk(ke - kb, first)) {
+                launch_sk<NF, 2>(sl, A, kb, ke, last);
                 return;
             }
         }
@@ -1497,6 +1545,17 @@ private:
     void launch_fused2_shape(Slab& sl, const sfk::JacobiArgs<T, NF>& A, int kb, int ke, bool first, bool last) {
         // 2x2 output vectors per thread: measured best of 1x1, 2x1, 1x2, 2x2, 4x2 (4x2 spills)
         launch_fused2<NF, NT, 2, 2, SRC>(sl, A, kb, ke, first, last);
+    }
+
+    // Sweeps fused into the launch that starts at iteration `it` of a K-sweep solve: 3 where the S-sweep kernel is in
+    // use (never the first pass of a solve, whose iterate is caller data / zero / a source; a remainder of four goes
+    // as 2 + 2), else 2 where pairs can be fused, else 1.
+    int sweeps_in_launch(int it, int K, bool continued) const {
+        const bool pair = can_fuse2() && it + 2 <= K;
+        const int left = K - it;
+        const bool triple = pair && (it > 0 || continued) && sk_max_sweeps() >= 3 && left >= 3 && left != 4 &&
+                            can_sk(nzl_, false);
+        return triple ? 3 : (pair ? 2 : 1);
     }
 
     // K Jacobi sweeps on NF fields at once; scratch buffers are swapped into the slots.
@@ -1535,7 +1594,10 @@ private:
         int it = 0;
         while (it < K) {
             const bool pair = can_fuse2() && it + 2 <= K;
-            const int step = pair ? 2 : 1;
+            // three sweeps per pass where the S-sweep kernel is in use (never the first pass of a solve, whose iterate
+            // is caller data; a remainder of four goes as 2 + 2)
+            const int step = sweeps_in_launch(it, K, continued);
+            const bool triple = step == 3;
             x_is_zero_ = x_zero && it == 0 && pair;  // the first fused pair then loads no x at all
             if (!pair || trap_m_ <= 1 || tj >= trap_m_ || nzl_ <= 2 * (G_ + 2 * tj) + 2) tj = 0;
             trap_extra_ = (pair && P_ > 1 && G_ == 2) ? 2 * tj : 0;
@@ -1550,7 +1612,9 @@ private:
                 }
                 A.a = a;
                 A.inv = inv;
-                if (pair)
+                if (triple)
+                    launch_jacobi3<NF>(sl, A, kb, ke, it + step == K);
+                else if (pair)
                     launch_jacobi2<NF>(sl, A, kb, ke, it == 0 && !continued, it + step == K);
                 else
                     launch_jacobi<NF>(sl, A, kb, ke, it == 0 && !continued, it + step == K);
@@ -1740,7 +1804,8 @@ private:
     int nzl_ = 0, lead_ = 0, px_ = 0, nplanes_ = 0, kchunk_ = 0, jacobi_mode_ = 2, tx_override_ = 0, nt_mode_ = 2, rb_shape_ = 0;
     bool ishell_skip_ = true, advect_lds_ = false, zero_skip_ = true, x_is_zero_ = false, fuse_src_ = true;
     int fuse2_ = 1, kc2_ = 32;
-    int march_k_ = 1, march_tj_ = 8, march_kc_ = 0, march_wg_per_cu_ = 1, march_min_planes_ = 12, march_ahead_ = 0;
+    int march_k_ = 1, march_min_planes_ = 12;
+    int sk_s_ = 3, sk_cfg_ = 0, sk_kc_ = 0, sk_wgcu_ = 0;
     long plane_ = 0, field_elems_ = 0;
     std::vector<Slab> slabs_;
     ncclComm_t comm_ = nullptr;
@@ -1819,8 +1884,10 @@ int sf_create(sf_ctx** out, const sf_params* p) {
         std::unique_ptr<sf_ctx> ctx(new sf_ctx);
         if (p->dtype == SF_F32)
             ctx->impl.reset(new Solver<float>(*p));
+#ifndef SF_NO_F64  // (experimental builds leave the fp64 instantiation out to halve the compile time)
         else if (p->dtype == SF_F64)
             ctx->impl.reset(new Solver<double>(*p));
+#endif
         else
             throw Failure{SF_ERR_INVALID, "dtype must be SF_F32 or SF_F64"};
         *out = ctx.release();

@@ -57,22 +57,23 @@ __device__ __forceinline__ void stv(T* p, typename VecT<T>::type v) {
 // Value of the neighbouring lane across the whole 64-lane wave, as a DPP move (v_mov_b32 wave_shr:1 /
 // wave_shl:1 — a VALU modifier on gfx9-family ISAs incl. gfx950, no LDS round trip as ds_bpermute has).
 // lane_up: lane l receives lane l-1 (lane 0 receives 0); lane_dn: lane l receives lane l+1 (lane 63: 0).
+// (bound_ctrl: a lane without a source reads 0, so the move needs no initialised destination.)
 __device__ __forceinline__ float lane_up(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
 }
 __device__ __forceinline__ float lane_dn(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
 }
 __device__ __forceinline__ double lane_up(double v) {
     const long long b = __builtin_bit_cast(long long, v);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffLL), 0x138, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x138, 0xf, 0xf, false);
+    const int lo = __builtin_amdgcn_mov_dpp((int)(b & 0xffffffffLL), 0x138, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp((int)(b >> 32), 0x138, 0xf, 0xf, true);
     return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
 }
 __device__ __forceinline__ double lane_dn(double v) {
     const long long b = __builtin_bit_cast(long long, v);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffLL), 0x130, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x130, 0xf, 0xf, false);
+    const int lo = __builtin_amdgcn_mov_dpp((int)(b & 0xffffffffLL), 0x130, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp((int)(b >> 32), 0x130, 0xf, 0xf, true);
     return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
 }
 
@@ -931,38 +932,8 @@ __global__ void __launch_bounds__(256, SF_J2_WAVES) jacobi2_kernel(Geom g, Jacob
 #undef SF_DIST
 }
 
-// Register-resident k-marching form of the two-sweep kernel (2.5-D temporal blocking, wave-autonomous).
-//
-// Why: jacobi2_kernel recomputes the first sweep on a 12-position cross per 4 outputs (3x) and requests 36 vectors per
-// 4 outputs (9 x-loads per output): at 512^3 it moves 3.6 TB/s of real HBM traffic, bound by instruction issue and
-// the L1 / texture-address path at two waves per SIMD, not by HBM. Here a LANE owns one vector column and TJ
-// consecutive rows and marches along k: the j+-1 neighbours are the lane's own registers, the i+-1 neighbours come
-// from the adjacent lanes (DPP), the k+-1 neighbours are the planes it has just visited. Per output vector:
-// (TJ+4)/TJ loads of x, (TJ+2)/TJ of x0, (TJ+2)/TJ first-sweep evaluations (TJ = 8: 1.5 / 1.25 / 1.25 against
-// 9 / 3 / 3), no LDS, no barrier, no divergent loads. The register file (512 KB per CU) is the staging buffer: the
-// 160 KB LDS would hold fewer planes than the registers do, and nothing is shared between waves — each wave takes
-// SF_OVL_OUT consecutive (row group, vector) items of the plane in memory order in lanes SF_OVL_LO.., the outer lanes
-// only feed the shuffles (the overlapped mapping of jacobi2_kernel), so rows of any width fill the waves.
-//   plane kk of the march:  loads x(kk+2), x0(kk+1) go out first (one step ahead of their use);
-//                           y(kk)  = J(x)(kk) on rows j0-1 .. j0+TJ   from x(kk-1), x(kk), x(kk+1), x0(kk)
-//                           x''(kk-1) on rows j0 .. j0+TJ-1           from y(kk-2), y(kk-1), y(kk), x0(kk-1)
-// A chunk of KC output planes costs KC+2 first-sweep planes and KC+4 planes of x (the chunk ends), so chunks are
-// long (>= 16 planes) and there are just enough of them to fill the chip a whole number of times (launcher).
-// The first sweep's set_bnd is applied in registers exactly as in jacobi2_kernel: bit-identical results.
-// Handles the plain pairs of a lin_solve (x already swept once: i-shell recomputed, ishell_mem == 0); the first pair
-// (caller data on the i-shell, folded add_source, implicit zero) and the thin boundary launches of a decomposed grid
-// stay with jacobi2_kernel.
-struct MarchMap {
-    int ncol;          // waves per chunk (columns of SF_OVL_OUT items)
-    int band;          // workgroups per XCD band (grid = 8 x band x nchunks)
-    int kc;            // output planes per chunk
-    unsigned nvec_magic;
-    int nrg;           // row groups = ceil(N / TJ)
-};
-
-
-// Lane vector of the marching kernel: WL cells (8 bytes: two floats / one double by default — half the register state
-// per lane of the 16-byte vectors used elsewhere, which is what lets two waves share a SIMD; see jacobi2k_kernel).
+// Lane vector of the marching kernel (jacobi_sk_kernel below): WL cells = 8 bytes (two floats / one double) — half the
+// register state per lane of the 16-byte vectors used elsewhere, which is what lets two waves share a SIMD.
 template <class T, int WL>
 struct LaneVec {
     typedef T type __attribute__((ext_vector_type(WL)));
@@ -1068,160 +1039,308 @@ __device__ __forceinline__ void j2k_shells(__amdgpu_buffer_rsrc_t rm, __amdgpu_b
     }
 }
 
-// One plane of the march. The planes live in four-slot register rings (x: kk-1, kk, kk+1 and the plane in flight;
-// y: kk-2, kk-1, kk and a free slot; x0 likewise); PH = kk mod 4 is a compile-time constant in the four-fold
-// unrolled loop, so a "rotation" is a renaming and costs no instruction — and, more important, nothing has to wait
-// for the plane in flight before the step that consumes it.
-// The steady state must be free of branches around memory operations: hipcc merges its s_waitcnt bookkeeping at every
-// join by taking the stricter count, and a "stores issued / not issued" or "loads issued / not issued" join made
-// every step wait for its own stores to drain. Hence: the requests of step (1) are unconditional (the plane index is
-// clamped instead), OUT (whether this step has a second-sweep plane to produce: not in the first two steps of a
-// chunk) and WALLS / ISH (whether this wave ever touches a j / k wall; whether the i-shell is written) are template
-// parameters, and the loop is left by breaks, never re-joined.
-template <class T, int WL, bool NT, int TJ, int PH, bool OUT, bool WALLS, bool ISH>
-__device__ __forceinline__ void j2k_step(const Geom& g, typename LaneVec<T, WL>::type (&xr)[4][TJ + 4],
-                                         typename LaneVec<T, WL>::type (&yr)[4][TJ + 2],
-                                         typename LaneVec<T, WL>::type (&sr)[4][TJ + 2],
-                                         const unsigned (&rowb)[TJ + 4], const T* __restrict__ x,
-                                         const T* __restrict__ x0, T* __restrict__ xn, int kk, T a, T inv, T sx, T sy,
-                                         T sz, int j0, bool first_vec, bool last_vec, bool active) {
+// ---------------------------------------------------------------------------------------------
+// S fused sweeps per pass through HBM (S = 2 or 3), k-marching, LDS halo exchange between the waves of a workgroup.
+//
+// Why (measured, profiles/r02_pair_kernel_issue.md): jacobi2_kernel recomputes the first sweep on a 12-position cross
+// per 4 outputs and requests 36 vectors per 4 outputs; at 512^3 it is bound by instruction issue and the L1 path at two
+// waves per SIMD (3.6 TB/s of HBM traffic). A first k-marching form (a lane owns a column of rows, j+-1 in its own
+// registers, i+-1 by DPP, k+-1 by marching; 2.2x fewer instructions) reached 6.1 TB/s of fabric traffic with a third
+// of its reads being overlap rows and chunk ends: memory-bound. So the lever left is bytes requested per sweep:
+//   * S sweeps per pass: x, x0 read once and x^(S) written once for S sweeps (3 words per cell / S);
+//   * the NW waves of a workgroup are stacked in j, each owning TJ rows of the same 64-lane column: the row above /
+//     below a wave's rows — of x and of every intermediate sweep level — comes from its neighbour wave through LDS
+//     (two 8-byte rows per level, wave and step, double-buffered, ONE barrier per step), so inside a workgroup no row
+//     is loaded twice and no intermediate value is computed twice. Only the workgroup's outer S rows per side (and S
+//     lanes per side of each wave, and S-1 planes per chunk end per level) are redundant: they are computed by
+//     everybody's code and simply not stored (a wave never branches on its position: the barrier needs lockstep).
+//   * per lane: register rings of four planes for x, x0 and each intermediate level (TJ rows of 8 bytes); ring
+//     positions are compile-time constants of the four-fold unrolled march (PH = step mod 4).
+// Step kk of the march (kk = k0-S+1 .. k1+S-2):   requests x(kk+2), x0(kk+1);
+//   level l = 1..S computes plane kk-l+1 from level l-1 (x for l = 1) on planes kk-l, kk-l+1, kk-l+2, rows -1 and TJ
+//   from LDS (published one step earlier); level S is stored. Level l starts 2(l-1) steps into the chunk.
+// set_bnd between sweeps is applied in registers exactly as in jacobi2_kernel (i: sx*, j/k walls: sy*, sz* of the
+// adjacent interior value), so the result is bit-identical to S separate sweeps.
+// Mapping: a j-block holds V = NW*TJ - 2S output rows; the (j-block, vector) items are numbered in memory order and a
+// workgroup takes 64-2S consecutive ones in lanes S..63-S (the overlapped mapping of jacobi2_kernel, any row width).
+// (left + right) of a two-cell lane vector whose i-neighbours sit in the adjacent lanes: e0 = c1[lane-1] + c1,
+// e1 = c0 + c0[lane+1]. For float the lane shift rides on the add itself (v_add_f32 with a DPP source: two
+// instructions instead of two DPP moves, a packed add and their wait states). Same operands, same IEEE sums.
+// The leading s_nop covers the "VALU write -> DPP read" hazard, which hipcc cannot see inside an asm statement.
+__device__ __forceinline__ void lr_sum2(float c0, float c1, float& e0, float& e1) {
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %2, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %1, %3, %3 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+        : "=&v"(e0), "=&v"(e1)
+        : "v"(c1), "v"(c0));
+}
+
+struct SkMap {
+    int ncb;    // column blocks (workgroups per chunk)
+    int band;   // workgroups per XCD band (grid = 8 x band x nchunks*NF)
+    int kc;     // output planes per chunk
+    int njb;    // j-blocks
+    unsigned nvec_magic;
+};
+
+template <class T, int WL, int S, int TJ, int NW>
+struct SkShared {
+    typename LaneVec<T, WL>::type edge[2][S][NW][2][64];  // [buffer][level 0..S-1][wave][first/last row][lane]
+};
+
+template <class T, int WL, bool NT, int S, int TJ, int NW, int PH, int NACT, bool WALLS, bool ISH, bool ROWEND>
+__device__ __forceinline__ void jsk_step(const Geom& g, SkShared<T, WL, S, TJ, NW>& sh,
+                                         typename LaneVec<T, WL>::type (&xr)[4][TJ],
+                                         typename LaneVec<T, WL>::type (&yr)[S - 1][4][TJ],
+                                         typename LaneVec<T, WL>::type (&sr)[4][TJ], const unsigned (&rowb)[TJ],
+                                         const unsigned (&rowst)[TJ], const T* __restrict__& px,
+                                         const T* __restrict__& ps0, T* __restrict__& pout, int kk, T a, T inv, T sx,
+                                         T sy, T sz, int jrow0, int wave, int lane, bool first_vec, bool last_vec) {
     typedef typename LaneVec<T, WL>::type VW;
-    constexpr int RX = TJ + 4, RY = TJ + 2;
-    constexpr int XA = (PH + 0) & 3, XB = (PH + 1) & 3, XC = (PH + 2) & 3, XD = (PH + 3) & 3;
-    constexpr int YA = (PH + 0) & 3, YB = (PH + 1) & 3, YC = (PH + 2) & 3;
-    constexpr int SB = (PH + 0) & 3, SC = (PH + 1) & 3, SD = (PH + 2) & 3;
     const int N = g.N;
     const int kmax = g.np - 1;
-    // (1) requests for the next step: x(kk+2), x0(kk+1)
+    constexpr int RB = (PH + 1) & 1, WB = PH & 1;  // LDS buffer read (written one step ago) / written in this step
+    // (1) requests for the next step: x(kk+2), x0(kk+1). px / ps0 point at those planes and advance by one plane per
+    // step (held at the last stored plane: the values requested beyond it are never used)
     {
-        int kx = kk + 2, ks = kk + 1;
-        kx = kx > kmax ? kmax : kx;
-        ks = ks > kmax ? kmax : ks;
-        const __amdgpu_buffer_rsrc_t rd = plane_rsrc(x + (long)kx * g.plane);
-        const __amdgpu_buffer_rsrc_t rs = plane_rsrc(x0 + (long)ks * g.plane);
+        const __amdgpu_buffer_rsrc_t rd = plane_rsrc(px);
+        const __amdgpu_buffer_rsrc_t rs = plane_rsrc(ps0);
+        px += (kk + 2 < kmax) ? g.plane : 0;
+        ps0 += (kk + 1 < kmax) ? g.plane : 0;
 #pragma unroll
-        for (int r = 0; r < RX; ++r) xr[XD][r] = buf_load<T, WL>(rd, rowb[r]);
+        for (int r = 0; r < TJ; ++r) xr[(PH + 2) & 3][r] = buf_load<T, WL>(rd, rowb[r]);
 #pragma unroll
-        for (int r = 0; r < RY; ++r) sr[SD][r] = buf_load<T, WL>(rs, rowb[r + 1]);
+        for (int r = 0; r < TJ; ++r) sr[(PH + 1) & 3][r] = buf_load<T, WL>(rs, rowb[r]);
+    }
+    // (2) the neighbours' edge rows of every active source level (published in the previous step)
+    const int wlo = wave > 0 ? wave - 1 : 0, whi = wave < NW - 1 ? wave + 1 : NW - 1;
+    VW hm[S], hp[S];
+#pragma unroll
+    for (int l = 1; l <= NACT; ++l) {
+        hm[l - 1] = sh.edge[RB][l - 1][wlo][1][lane];
+        hp[l - 1] = sh.edge[RB][l - 1][whi][0][lane];
     }
     __builtin_amdgcn_sched_barrier(0);
-    // (2) first sweep: y(kk) on rows j0-1 .. j0+TJ
+    // (3) levels 1 .. NACT
 #pragma unroll
-    for (int r = 0; r < RY; ++r) {
-        const VW cc = xr[XB][r + 1];
-        const T up = lane_up(cc[WL - 1]);
-        const T dn = lane_dn(cc[0]);
-        const T xm = first_vec ? sx * cc[0] : up;
-        const T xp = last_vec ? sx * cc[WL - 1] : dn;
-        const VW jm = xr[XB][r], jp = xr[XB][r + 2], km = xr[XA][r + 1], kp = xr[XC][r + 1], s = sr[SC][r];
-        VW y;
-#pragma unroll
-        for (int e = 0; e < WL; ++e) {
-            const T left = (e == 0) ? xm : cc[e > 0 ? e - 1 : 0];
-            const T right = (e == WL - 1) ? xp : cc[e < WL - 1 ? e + 1 : WL - 1];
-            y[e] = (s[e] + a * (((left + right) + (jm[e] + jp[e])) + (km[e] + kp[e]))) * inv;
-        }
-        yr[YC][r] = y;
-    }
-    // (3) second sweep: x''(kk-1) on rows j0 .. j0+TJ-1
-    if constexpr (OUT) {
-        const int ko = kk - 1;
-        const int kg = g.kg0 + ko;
-        const bool klo = WALLS && g.wall_lo && kg == 1, khi = WALLS && g.wall_hi && kg == N;  // wave-uniform
-        T* __restrict__ po = xn + (long)ko * g.plane;
+    for (int l = 1; l <= NACT; ++l) {
+        // source level l-1 on planes kk-l (km), kk-l+1 (centre), kk-l+2 (kp); this level's plane is kk-l+1
+        const int pl = kk - l + 1;
+        const int kg = g.kg0 + pl;
+        // k walls are handled in every instantiation: wave-uniform tests, true in at most S-1 steps per chunk end
+        const bool klo = l >= 2 && g.wall_lo && kg == 1, khi = l >= 2 && g.wall_hi && kg == N;
+        T* __restrict__ po = pout;  // plane kk-S+1: only used by level S
         const __amdgpu_buffer_rsrc_t rc = plane_rsrc(po);
 #pragma unroll
         for (int r = 0; r < TJ; ++r) {
-            const int j = j0 + r;
-            const VW yc = yr[YB][r + 1];
-            const T up = lane_up(yc[WL - 1]);
-            const T dn = lane_dn(yc[0]);
-            const T ym = first_vec ? sx * yc[0] : up;
-            const T yp = last_vec ? sx * yc[WL - 1] : dn;
-            VW jm = yr[YB][r], jp = yr[YB][r + 2], km = yr[YA][r + 1], kp = yr[YC][r + 1];
-            if constexpr (WALLS) {  // first-sweep set_bnd on the j / k walls
-                if (j == 1) jm = sy * yc;
-                if (j == N) jp = sy * yc;
-                if (klo) km = sz * yc;
-                if (khi) kp = sz * yc;
+            VW cc, km, kp, jm, jp;
+            if (l == 1) {
+                cc = xr[(PH + 0) & 3][r];
+                km = xr[(PH + 3) & 3][r];
+                kp = xr[(PH + 1) & 3][r];
+                jm = r > 0 ? xr[(PH + 0) & 3][r > 0 ? r - 1 : 0] : hm[0];
+                jp = r < TJ - 1 ? xr[(PH + 0) & 3][r < TJ - 1 ? r + 1 : 0] : hp[0];
+            } else {
+                const int q = l >= 2 ? l - 2 : 0;
+                cc = yr[q][(PH + 5 - l) & 3][r];
+                km = yr[q][(PH + 4 - l) & 3][r];
+                kp = yr[q][(PH + 6 - l) & 3][r];
+                jm = r > 0 ? yr[q][(PH + 5 - l) & 3][r > 0 ? r - 1 : 0] : hm[l - 1];
+                jp = r < TJ - 1 ? yr[q][(PH + 5 - l) & 3][r < TJ - 1 ? r + 1 : 0] : hp[l - 1];
             }
-            const VW s = sr[SB][r + 1];
+            const int j = jrow0 + r;
+            // (left + right): the i-neighbours of the lane's end cells live in the adjacent lanes; at a row end they
+            // are the i-shell cells sx * (end cell) instead (ROWEND: does this workgroup hold a row end at all?)
+            VW lr;
+            if constexpr (WL == 2 && sizeof(T) == 4) {
+                T e0, e1;
+                lr_sum2(cc[0], cc[1], e0, e1);
+                if constexpr (ROWEND) {
+                    e0 = first_vec ? sx * cc[0] + cc[1] : e0;
+                    e1 = last_vec ? cc[0] + sx * cc[1] : e1;
+                }
+                lr[0] = e0;
+                lr[1] = e1;
+            } else {
+                const T up = lane_up(cc[WL - 1]);
+                const T dn = lane_dn(cc[0]);
+                const T cm = (ROWEND && first_vec) ? sx * cc[0] : up;
+                const T cp = (ROWEND && last_vec) ? sx * cc[WL - 1] : dn;
+#pragma unroll
+                for (int e = 0; e < WL; ++e) {
+                    const T left = (e == 0) ? cm : cc[e > 0 ? e - 1 : 0];
+                    const T right = (e == WL - 1) ? cp : cc[e < WL - 1 ? e + 1 : WL - 1];
+                    lr[e] = left + right;
+                }
+            }
+            if (l >= 2) {  // set_bnd of the source level on the j / k walls
+                if (WALLS) {
+                    if (j == 1) jm = sy * cc;
+                    if (j == N) jp = sy * cc;
+                }
+                if (klo) km = sz * cc;
+                if (khi) kp = sz * cc;
+            }
+            const VW s = sr[(PH + 5 - l) & 3][r];
             VW o;
 #pragma unroll
-            for (int e = 0; e < WL; ++e) {
-                const T left = (e == 0) ? ym : yc[e > 0 ? e - 1 : 0];
-                const T right = (e == WL - 1) ? yp : yc[e < WL - 1 ? e + 1 : WL - 1];
-                o[e] = (s[e] + a * (((left + right) + (jm[e] + jp[e])) + (km[e] + kp[e]))) * inv;
-            }
-            if (active && j <= N) {
-                buf_store<T, WL, NT>(rc, rowb[r + 2], o);
-                if constexpr (WALLS)
-                    j2k_shells<T, WL>(plane_rsrc(po - g.plane), rc, plane_rsrc(po + g.plane), rowb[r + 2], rowb[r + 1],
-                                      rowb[r + 3], o, sx, sy, sz, j == 1, j == N, klo, khi, ISH && first_vec,
-                                      ISH && last_vec);
-                else if constexpr (ISH) {  // no wall near this wave: only the i = 0 / N+1 cells of the row
-                    if (first_vec) buf_store1<T>(rc, rowb[r + 2] - (unsigned)sizeof(T), sx * o[0]);
-                    if (last_vec) buf_store1<T>(rc, rowb[r + 2] + WL * (unsigned)sizeof(T), sx * o[WL - 1]);
+            for (int e = 0; e < WL; ++e) o[e] = (s[e] + a * ((lr[e] + (jm[e] + jp[e])) + (km[e] + kp[e]))) * inv;
+            if (l < S) {
+                yr[l - 1 < S - 1 ? l - 1 : 0][(PH + 5 - l) & 3][r] = o;
+            } else {
+                // rowst[r]: the row's store offset, or an out-of-range one if this lane / row must not store (feeder
+                // lane, outer S rows of the workgroup's tile, row beyond N)
+                constexpr unsigned OOB = 0xFFFFFF00u;
+                const bool valid = rowst[r] != OOB;
+                // No branch around the stores (a "stored / not stored" join makes hipcc wait for every older store at
+                // the next s_waitcnt): lanes that must not store carry an offset beyond the resource's range, and the
+                // hardware drops an out-of-range buffer store.
+                if constexpr (!WALLS) {
+                    const unsigned offv = rowst[r];
+                    const unsigned offlo = (ISH && valid && first_vec) ? rowb[r] - (unsigned)sizeof(T) : OOB;
+                    const unsigned offhi = (ISH && valid && last_vec) ? rowb[r] + WL * (unsigned)sizeof(T) : OOB;
+                    buf_store<T, WL, NT>(rc, offv, o);
+                    if constexpr (ISH) {  // no j wall near this workgroup: only the i = 0 / N+1 cells of the row
+                        buf_store1<T>(rc, offlo, sx * o[0]);
+                        buf_store1<T>(rc, offhi, sx * o[WL - 1]);
+                    }
+                    // first / last plane of a wall slab (wave-uniform, one step per chunk end): the k face of this row
+                    // and, with the i-shell, its two i-k edge cells — the expressions of emit_shells
+                    const bool kslo = g.wall_lo && kg == 1, kshi = g.wall_hi && kg == N;
+                    if (kslo | kshi) {
+                        const T half = T(0.5);
+                        VW t;
+#pragma unroll
+                        for (int e = 0; e < WL; ++e) t[e] = sz * o[e];
+                        const T elo = half * (sz * o[0] + sx * o[0]), ehi = half * (sz * o[WL - 1] + sx * o[WL - 1]);
+                        if (kslo) {
+                            const __amdgpu_buffer_rsrc_t rk = plane_rsrc(po - g.plane);
+                            buf_store<T, WL, false>(rk, offv, t);
+                            if constexpr (ISH) {
+                                buf_store1<T>(rk, offlo, elo);
+                                buf_store1<T>(rk, offhi, ehi);
+                            }
+                        }
+                        if (kshi) {
+                            const __amdgpu_buffer_rsrc_t rk = plane_rsrc(po + g.plane);
+                            buf_store<T, WL, false>(rk, offv, t);
+                            if constexpr (ISH) {
+                                buf_store1<T>(rk, offlo, elo);
+                                buf_store1<T>(rk, offhi, ehi);
+                            }
+                        }
+                    }
+                } else if (valid) {
+                    buf_store<T, WL, NT>(rc, rowb[r], o);
+                    const bool kslo = g.wall_lo && kg == 1, kshi = g.wall_hi && kg == N;
+                    if ((j == 1) | (j == N) | kslo | kshi | (ISH && (first_vec | last_vec))) {
+                        const unsigned pxb = (unsigned)g.px * (unsigned)sizeof(T);
+                        j2k_shells<T, WL>(plane_rsrc(po - g.plane), rc, plane_rsrc(po + g.plane), rowb[r], rowb[r] - pxb,
+                                          rowb[r] + pxb, o, sx, sy, sz, j == 1, j == N, kslo, kshi, ISH && first_vec,
+                                          ISH && last_vec);
+                    }
                 }
             }
         }
     }
+    // (4) publish this wave's edge rows: x(kk+1) and every intermediate level computed in this step
+    sh.edge[WB][0][wave][0][lane] = xr[(PH + 1) & 3][0];
+    sh.edge[WB][0][wave][1][lane] = xr[(PH + 1) & 3][TJ - 1];
+#pragma unroll
+    for (int l = 1; l < S; ++l)
+        if (l <= NACT) {
+            sh.edge[WB][l][wave][0][lane] = yr[l - 1][(PH + 5 - l) & 3][0];
+            sh.edge[WB][l][wave][1][lane] = yr[l - 1][(PH + 5 - l) & 3][TJ - 1];
+        }
+    if (NACT == S) pout += g.plane;
+    // (5) one barrier per step (LDS only: the global requests stay in flight across it)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <class T, int WL, bool NT, int TJ, bool WALLS, bool ISH>
-__device__ __forceinline__ void j2k_march(const Geom& g, const unsigned (&rowb)[TJ + 4], const T* __restrict__ x,
-                                          const T* __restrict__ x0, T* __restrict__ xn, int k0, int k1, T a, T inv,
-                                          T sx, T sy, T sz, int j0, bool first_vec, bool last_vec, bool active) {
+template <class T, int WL, bool NT, int S, int TJ, int NW, bool WALLS, bool ISH, bool ROWEND>
+__device__ __forceinline__ void jsk_march(const Geom& g, SkShared<T, WL, S, TJ, NW>& sh, const unsigned (&rowb)[TJ],
+                                          const unsigned (&rowst)[TJ], const T* __restrict__ x,
+                                          const T* __restrict__ x0, T* __restrict__ xn, int k0, int k1, T a, T inv, T sx,
+                                          T sy, T sz, int jrow0, int wave, int lane, bool first_vec, bool last_vec) {
     typedef typename LaneVec<T, WL>::type VW;
-    constexpr int RX = TJ + 4, RY = TJ + 2;
+    static_assert(S == 2 || S == 3, "two or three fused sweeps");
     const int kmax = g.np - 1;
     auto plane_of_k = [&](const T* base, int kl) -> __amdgpu_buffer_rsrc_t {
         kl = kl < 0 ? 0 : (kl > kmax ? kmax : kl);
         return plane_rsrc(base + (long)kl * g.plane);
     };
-    // rings, phase 0 at kk = k0-1: x slots (A,B,C,D) = (0,1,2,3); y (A,B,C) = (0,1,2); x0 (B,C,D) = (0,1,2)
-    VW xr[4][RX], yr[4][RY], sr[4][RY];
+    VW xr[4][TJ], yr[S - 1][4][TJ], sr[4][TJ];
+    int kk = k0 - S + 1;  // first step; ring phase 0
     {
-        const __amdgpu_buffer_rsrc_t pa = plane_of_k(x, k0 - 2), pb = plane_of_k(x, k0 - 1), pc = plane_of_k(x, k0);
-        const __amdgpu_buffer_rsrc_t ps = plane_of_k(x0, k0 - 1);
+        // planes kk-1, kk, kk+1 of x in ring slots 3, 0, 1; x0(kk) in slot 0
+        const __amdgpu_buffer_rsrc_t pa = plane_of_k(x, kk - 1), pb = plane_of_k(x, kk), pc = plane_of_k(x, kk + 1);
+        const __amdgpu_buffer_rsrc_t ps = plane_of_k(x0, kk);
 #pragma unroll
-        for (int r = 0; r < RX; ++r) {
-            xr[0][r] = buf_load<T, WL>(pa, rowb[r]);
-            xr[1][r] = buf_load<T, WL>(pb, rowb[r]);
-            xr[2][r] = buf_load<T, WL>(pc, rowb[r]);
+        for (int r = 0; r < TJ; ++r) {
+            xr[3][r] = buf_load<T, WL>(pa, rowb[r]);
+            xr[0][r] = buf_load<T, WL>(pb, rowb[r]);
+            xr[1][r] = buf_load<T, WL>(pc, rowb[r]);
+            sr[0][r] = buf_load<T, WL>(ps, rowb[r]);
         }
-#pragma unroll
-        for (int r = 0; r < RY; ++r) sr[1][r] = buf_load<T, WL>(ps, rowb[r + 1]);
+        // the first step reads the edges of x(kk) from buffer 1
+        sh.edge[1][0][wave][0][lane] = xr[0][0];
+        sh.edge[1][0][wave][1][lane] = xr[0][TJ - 1];
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
-#define SF_J2K_STEP(PH_, OUT_)                                                                                     \
-    j2k_step<T, WL, NT, TJ, PH_, OUT_, WALLS, ISH>(g, xr, yr, sr, rowb, x, x0, xn, kk, a, inv, sx, sy, sz, j0,      \
-                                                   first_vec, last_vec, active)
-    int kk = k0 - 1;
-    SF_J2K_STEP(0, false);  // y(k0-1)
+    // running plane pointers: x(kk+2), x0(kk+1) (k0 >= 1, so both indices are >= 0) and the output plane k0
+    const T* __restrict__ px = x + (long)(kk + 2 > kmax ? kmax : kk + 2) * g.plane;
+    const T* __restrict__ ps0 = x0 + (long)(kk + 1 > kmax ? kmax : kk + 1) * g.plane;
+    T* __restrict__ pout = xn + (long)k0 * g.plane;
+#define SF_SK_STEP(PH_, NACT_)                                                                                       \
+    jsk_step<T, WL, NT, S, TJ, NW, PH_, NACT_, WALLS, ISH, ROWEND>(g, sh, xr, yr, sr, rowb, rowst, px, ps0, pout, kk, a, \
+                                                                   inv, sx, sy, sz, jrow0, wave, lane, first_vec,      \
+                                                                   last_vec)
+    const int kend = k1 + S - 2;  // last step
+    SF_SK_STEP(0, 1);
     ++kk;
-    SF_J2K_STEP(1, false);  // y(k0)
+    SF_SK_STEP(1, 1);
     ++kk;
-    for (;;) {  // kk = k0+1 .. k1: y(kk) and x''(kk-1); a chunk has at least one plane, so k0+1 <= k1
-        SF_J2K_STEP(2, true);
-        if (++kk > k1) break;
-        SF_J2K_STEP(3, true);
-        if (++kk > k1) break;
-        SF_J2K_STEP(0, true);
-        if (++kk > k1) break;
-        SF_J2K_STEP(1, true);
-        if (++kk > k1) break;
+    if constexpr (S == 2) {
+        for (;;) {
+            SF_SK_STEP(2, 2);
+            if (++kk > kend) break;
+            SF_SK_STEP(3, 2);
+            if (++kk > kend) break;
+            SF_SK_STEP(0, 2);
+            if (++kk > kend) break;
+            SF_SK_STEP(1, 2);
+            if (++kk > kend) break;
+        }
+    } else {
+        SF_SK_STEP(2, 2);
+        ++kk;
+        SF_SK_STEP(3, 2);
+        ++kk;
+        for (;;) {
+            SF_SK_STEP(0, 3);
+            if (++kk > kend) break;
+            SF_SK_STEP(1, 3);
+            if (++kk > kend) break;
+            SF_SK_STEP(2, 3);
+            if (++kk > kend) break;
+            SF_SK_STEP(3, 3);
+            if (++kk > kend) break;
+        }
     }
-#undef SF_J2K_STEP
+#undef SF_SK_STEP
 }
 
-#ifndef SF_J2K_WAVES
-#define SF_J2K_WAVES 2
+#ifndef SF_SK_WAVES
+#define SF_SK_WAVES 2
 #endif
 
-template <class T, int NF, int WL, bool NT, int TJ, bool ISH>
-__global__ void __launch_bounds__(256, SF_J2K_WAVES) jacobi2k_kernel(Geom g, JacobiArgs<T, NF> A, int kb, int ke,
-                                                                     MarchMap m) {
-    constexpr int RX = TJ + 4;  // rows of x held per plane: j0-2 .. j0+TJ+1 (y: j0-1 .. j0+TJ)
+template <class T, int NF, int WL, bool NT, int S, int TJ, int NW, bool ISH>
+__global__ void __launch_bounds__(64 * NW, SF_SK_WAVES) jacobi_sk_kernel(Geom g, JacobiArgs<T, NF> A, int kb, int ke,
+                                                                         SkMap m) {
+    constexpr int P = 64 - 2 * S;       // productive lanes of a wave
+    constexpr int V = NW * TJ - 2 * S;  // output rows of a j-block
+    static_assert(V > 0, "tile too small for the sweep depth");
+    __shared__ SkShared<T, WL, S, TJ, NW> sh;
     const int N = g.N;
     const int nvec = N / WL;
     const int cb = (int)blockIdx.x * m.band + (int)blockIdx.y;  // column block; workgroup x runs on XCD group x
@@ -1236,18 +1355,18 @@ __global__ void __launch_bounds__(256, SF_J2K_WAVES) jacobi2k_kernel(Geom g, Jac
             f = (int)blockIdx.z / nchunk;
         }
     }
+    if (cb >= m.ncb) return;  // whole workgroups
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63;
-    const int col = cb * 4 + (tid >> 6);
-    if (col >= m.ncol) return;  // whole waves; nothing in this kernel crosses waves
-    const int total = m.nrg * nvec;
-    int t = col * SF_OVL_OUT + lane - SF_OVL_LO;
-    const bool active = t >= 0 && t < total && lane >= SF_OVL_LO && lane < SF_OVL_LO + SF_OVL_OUT;
+    const int wave = tid >> 6;
+    const int total = m.njb * nvec;
+    int t = cb * P + lane - S;
+    const bool active = t >= 0 && t < total && lane >= S && lane < 64 - S;
     t = t < 0 ? 0 : (t >= total ? total - 1 : t);  // feeder / padding lanes run on valid addresses
-    const int rg = nvec == 1 ? t : (int)__umulhi((unsigned)t, m.nvec_magic);
-    const int vec = t - rg * nvec;
-    const int j0 = 1 + rg * TJ;
+    const int jb = nvec == 1 ? t : (int)__umulhi((unsigned)t, m.nvec_magic);
+    const int vec = t - jb * nvec;
     const int i0 = 1 + WL * vec;
+    const int jrow0 = jb * V + 1 - S + wave * TJ;  // j of this lane's row 0 (may lie outside [0, N+1]: clamped below)
     const int k0 = kb + chunk * m.kc;
     const int k1 = (k0 + m.kc < ke) ? k0 + m.kc : ke;
 
@@ -1268,26 +1387,43 @@ __global__ void __launch_bounds__(256, SF_J2K_WAVES) jacobi2k_kernel(Geom g, Jac
     const T sy = (b == 2) ? T(-1) : T(1);
     const T sz = (b == 3) ? T(-1) : T(1);
 
-    // per-lane BYTE offsets of the rows inside a plane (32 bit: a plane is far below 2 GiB)
-    unsigned rowb[RX];
+    unsigned rowb[TJ];
 #pragma unroll
-    for (int r = 0; r < RX; ++r) {
-        int j = j0 - 2 + r;
+    for (int r = 0; r < TJ; ++r) {
+        int j = jrow0 + r;
         j = j < 0 ? 0 : (j > N + 1 ? N + 1 : j);
         rowb[r] = (unsigned)(j * g.px + (g.lead - 1) + i0) * (unsigned)sizeof(T);
     }
+    unsigned rowst[TJ];
+#pragma unroll
+    for (int r = 0; r < TJ; ++r) {
+        const int jt = wave * TJ + r;  // row inside the workgroup's tile: the outer S rows are not valid
+        rowst[r] = (active && jt >= S && jt < NW * TJ - S && jrow0 + r <= N) ? rowb[r] : 0xFFFFFF00u;
+    }
     const bool first_vec = (vec == 0), last_vec = (vec == nvec - 1);
-    // does this wave ever touch a j wall (fixed per lane for the whole march) or a k wall (first / last plane of a
-    // wall slab inside this chunk)? Most waves do not and take the instantiation without any wall code
-    const bool lane_jwall = (j0 <= 1) | (j0 + TJ - 1 >= N);
-    const bool kwall = (g.wall_lo && g.kg0 + k0 <= 1) | (g.wall_hi && g.kg0 + k1 - 1 >= N);
-    const bool wave_walls = kwall | (__builtin_amdgcn_ballot_w64(lane_jwall) != 0ull);
-    if (wave_walls)
-        j2k_march<T, WL, NT, TJ, true, ISH>(g, rowb, x, x0, xn, k0, k1, a, inv, sx, sy, sz, j0, first_vec, last_vec,
-                                            active);
+    // Does this WORKGROUP touch a j wall? (uniform over the workgroup, from its item range: every wave takes the same
+    // instantiation.) j walls live in the first / last j-block. k walls are cheap wave-uniform tests in every step.
+    int tlo = cb * P, thi = cb * P + P - 1;
+    thi = thi >= total ? total - 1 : thi;
+    const int jb_lo = nvec == 1 ? tlo : (int)__umulhi((unsigned)tlo, m.nvec_magic);
+    const int jb_hi = nvec == 1 ? thi : (int)__umulhi((unsigned)thi, m.nvec_magic);
+    const bool jwall = jb_lo == 0 || (jb_hi + 1) * V + S >= N;  // a tile row (halo included) is j = 1 or j = N
+    // ... and a row end (a lane, feeder lanes included, whose vector is the first or last of its row)? Uniform as well.
+    int flo = cb * P - S, fhi = cb * P + P - 1 + S;
+    flo = flo < 0 ? 0 : flo;
+    fhi = fhi >= total ? total - 1 : fhi;
+    const int fb_lo = nvec == 1 ? flo : (int)__umulhi((unsigned)flo, m.nvec_magic);
+    const int fb_hi = nvec == 1 ? fhi : (int)__umulhi((unsigned)fhi, m.nvec_magic);
+    const bool rowend = fb_lo != fb_hi || flo - fb_lo * nvec == 0 || fhi - fb_hi * nvec == nvec - 1;
+    if (jwall)
+        jsk_march<T, WL, NT, S, TJ, NW, true, ISH, true>(g, sh, rowb, rowst, x, x0, xn, k0, k1, a, inv, sx, sy, sz, jrow0,
+                                                         wave, lane, first_vec, last_vec);
+    else if (rowend)
+        jsk_march<T, WL, NT, S, TJ, NW, false, ISH, true>(g, sh, rowb, rowst, x, x0, xn, k0, k1, a, inv, sx, sy, sz, jrow0,
+                                                          wave, lane, first_vec, last_vec);
     else
-        j2k_march<T, WL, NT, TJ, false, ISH>(g, rowb, x, x0, xn, k0, k1, a, inv, sx, sy, sz, j0, first_vec, last_vec,
-                                             active);
+        jsk_march<T, WL, NT, S, TJ, NW, false, ISH, false>(g, sh, rowb, rowst, x, x0, xn, k0, k1, a, inv, sx, sy, sz, jrow0,
+                                                           wave, lane, first_vec, last_vec);
 }
 
 // LDS-staged, k-marching form of the two-sweep kernel (2.5-D temporal blocking).
