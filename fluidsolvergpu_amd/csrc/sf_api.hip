@@ -99,6 +99,7 @@ public:
     virtual int lin_solve_launches(int iters) const = 0;
     virtual void snapshot(const int* fields, int nfields) = 0;
     virtual void snapshot_read(int index, void* host) = 0;
+    virtual void snapshot_read_planes(int index, int kb, int ke, void* host) = 0;
     virtual void tracers_set(int n, const void* xyz) = 0;
     virtual void tracers_advect() = 0;
     virtual void tracers_get(void* xyz, void* dens, void* speed) = 0;
@@ -268,8 +269,9 @@ public:
         graphs_ = env_int("SF_GRAPH", 0) != 0 && P_ == 1;
         march_k_ = env_int("SF_MARCH", 1);  // 0: the register-blocked pair kernel everywhere
         march_min_planes_ = env_int("SF_MARCH_MINP", 12);
+        march_min_cells_ = (long)env_int("SF_MARCH_MINCELLS_K", 6000) * 1000L;  // ~182^3
         sk_s_ = env_int("SF_SK_S", 3);
-        sk_cfg_ = env_int("SF_SK_CFG", 0);
+        sk_cfg_ = env_int("SF_SK_CFG", -1);  // tile shape: -1 automatic, 0..3 see SF_SK_CFGS
         sk_kc_ = env_int("SF_SK_KC", 0);
         sk_wgcu_ = env_int("SF_SK_WGCU", 0);
         SF_HIP(hipDeviceSynchronize());
@@ -798,19 +800,35 @@ public:
 
     // May run on another host thread: touches only the snapshot buffers, the output stream and snap_done.
     void snapshot_read(int index, void* host) override {
+        SF_REQUIRE(host != nullptr, "null host pointer");
+        // the planes this context is the owner of (shell planes on the end slabs), at their place in the GLOBAL array
+        const int kb = slabs_.front().geom.kg0 + G_ - (slabs_.front().geom.wall_lo ? 1 : 0);
+        const int ke = slabs_.back().geom.kg0 + G_ + nzl_ + (slabs_.back().geom.wall_hi ? 1 : 0);
+        const size_t S = (size_t)N_ + 2;
+        snapshot_read_planes(index, kb, ke, static_cast<T*>(host) + (size_t)kb * S * S);
+    }
+
+    // Planes [kb, ke) of snapshot `index` into a host array that holds exactly those planes (dense (N+2)^2 each).
+    void snapshot_read_planes(int index, int kb, int ke, void* host) override {
         SF_REQUIRE(index >= 0 && index < snap_count_, "snapshot index out of range");
         SF_REQUIRE(host != nullptr, "null host pointer");
+        SF_REQUIRE(kb < ke, "empty plane range");
         SF_HIP(hipSetDevice(device_));
         const size_t S = (size_t)N_ + 2;
+        bool any = false;
         for (Slab& sl : slabs_) {
             SF_HIP(hipStreamWaitEvent(sl.os, sl.snap_done, 0));
-            const int kb = sl.geom.kg0 + G_ - (sl.geom.wall_lo ? 1 : 0);
-            const int ke = sl.geom.kg0 + G_ + nzl_ + (sl.geom.wall_hi ? 1 : 0);
-            SF_HIP(hipMemcpy2DAsync(static_cast<T*>(host) + (size_t)kb * S * S, S * sizeof(T),
-                                    sl.snap[index] + (size_t)(kb - sl.geom.kg0) * plane_ + (lead_ - 1),
-                                    (size_t)px_ * sizeof(T), S * sizeof(T), S * (size_t)(ke - kb),
-                                    hipMemcpyDeviceToHost, sl.os));
+            const int ob = sl.geom.kg0 + G_ - (sl.geom.wall_lo ? 1 : 0);
+            const int oe = sl.geom.kg0 + G_ + nzl_ + (sl.geom.wall_hi ? 1 : 0);
+            const int b = std::max(kb, ob), e = std::min(ke, oe);
+            if (b >= e) continue;
+            any = true;
+            SF_HIP(hipMemcpy2DAsync(static_cast<T*>(host) + (size_t)(b - kb) * S * S, S * sizeof(T),
+                                    sl.snap[index] + (size_t)(b - sl.geom.kg0) * plane_ + (lead_ - 1),
+                                    (size_t)px_ * sizeof(T), S * sizeof(T), S * (size_t)(e - b), hipMemcpyDeviceToHost,
+                                    sl.os));
         }
+        SF_REQUIRE(any, "plane range not stored by this context");
         for (Slab& sl : slabs_) SF_HIP(hipStreamSynchronize(sl.os));
     }
 
@@ -1416,7 +1434,9 @@ private:
     // k-marching S-sweep kernel (sfk::jacobi_sk_kernel): the plain passes of a solve (iterate already swept once, so its
     // i-shell is recomputed in registers) on plane ranges long enough to march. SF_MARCH=0 switches it off.
     bool can_march_k(int nplanes, bool first) const {
-        return march_k_ != 0 && !first && ishell_skip_ && split_ == INT_MAX && nplanes >= march_min_planes_ && !x_is_zero_;
+        // small grids do not fill the chip with 512-thread workgroups of 48 rows (128^3: 9.0 vs 4.3 us/sweep)
+        return march_k_ != 0 && !first && ishell_skip_ && split_ == INT_MAX && nplanes >= march_min_planes_ &&
+               !x_is_zero_ && (long)N_ * N_ * nplanes >= march_min_cells_;
     }
 
     // S fused sweeps with LDS halo exchange (sfk::jacobi_sk_kernel). Same eligibility as the two-sweep marching kernel;
@@ -1424,10 +1444,25 @@ private:
     bool can_sk(int nplanes, bool first) const { return can_march_k(nplanes, first); }
     int sk_max_sweeps() const { return (march_k_ != 0 && P_ == 1) ? std::min(sk_s_, 3) : 2; }
 
+    int sk_chunks(int ncb, int np, int S) const {
+        const int max_chunks = std::max(1, np / 8);
+        double best = -1;
+        int nchunk = 1;
+        for (int c = 1; c <= max_chunks; ++c) {
+            const int kc = ceil_div(np, c);
+            const long total = (long)ncb * ceil_div(np, kc);
+            const double tm = (double)ceil_div(total, (long)num_cu_) * (kc + 2 * S - 2 + 2);
+            if (best < 0 || tm < best * 0.999) {
+                best = tm;
+                nchunk = c;
+            }
+        }
+        return nchunk;
+    }
     template <bool NT, int S, int TJ, int NW>
     void launch_sk_cfg(Slab& sl, const sfk::JacobiArgs<T, 1>& A, int kb, int ke, bool last) {
         constexpr int WL = W / 2;  // 8 bytes per lane
-        constexpr int V = NW * TJ - 2 * S, P = 64 - 2 * S;
+        constexpr int V = NW * TJ - 2 * S, P = 64 - 2 * ((S + WL - 1) / WL);
         const int nvec = N_ / WL;
         sfk::SkMap m{};
         m.njb = ceil_div(N_, V);
@@ -1440,21 +1475,9 @@ private:
         if (sk_kc_ > 0) {
             nchunk = ceil_div(np, sk_kc_);
         } else {
-            // a chunk costs 2S-2 extra steps: as few chunks as fill the chip a whole number of times
-            const long cap = (long)num_cu_ * (sk_wgcu_ > 0 ? sk_wgcu_ : (NW == 8 ? 1 : 2));
-            const int max_chunks = std::max(1, np / 8);
-            double best = -1;
-            nchunk = 1;
-            for (int c = 1; c <= max_chunks; ++c) {
-                const int kc = ceil_div(np, c);
-                const long total = (long)m.ncb * ceil_div(np, kc);
-                const long rounds = ceil_div(total, cap);
-                const double tm = (double)rounds * (kc + 2 * S - 2 + 3);
-                if (best < 0 || tm < best * 0.999) {
-                    best = tm;
-                    nchunk = c;
-                }
-            }
+            // The kernel is bound by the bytes a CU can request per unit time, so workgroups that share a CU share its
+            // rate: time ~ (workgroups per CU, rounded up) x (steps per chunk: kc + 2S-2, plus start-up).
+            nchunk = sk_chunks(m.ncb, np, S);
         }
         m.kc = ceil_div(np, nchunk);
         nchunk = ceil_div(np, m.kc);
@@ -1480,7 +1503,9 @@ private:
 #ifndef SF_SK_CFGS
 #define SF_SK_CFGS 1  // bit q: instantiate configuration q (0: 6 rows x 8 waves, 1: 4 x 4, 2: 6 x 4, 3: 4 x 8)
 #endif
-            const int cfg = ((SF_SK_CFGS >> sk_cfg_) & 1) ? sk_cfg_ : __builtin_ctz(SF_SK_CFGS);
+            int want = sk_cfg_;
+            if (want < 0) want = 0;  // 6 rows x 8 waves: measured best of the four at 256^3 ... 512^3, fp32 and fp64
+            const int cfg = ((SF_SK_CFGS >> want) & 1) ? want : __builtin_ctz(SF_SK_CFGS);
             if ((SF_SK_CFGS & 2) && cfg == 1) {
                 if constexpr ((SF_SK_CFGS & 2) != 0) {
                     if (nt)
@@ -1805,7 +1830,8 @@ private:
     bool ishell_skip_ = true, advect_lds_ = false, zero_skip_ = true, x_is_zero_ = false, fuse_src_ = true;
     int fuse2_ = 1, kc2_ = 32;
     int march_k_ = 1, march_min_planes_ = 12;
-    int sk_s_ = 3, sk_cfg_ = 0, sk_kc_ = 0, sk_wgcu_ = 0;
+    long march_min_cells_ = 6000000;
+    int sk_s_ = 3, sk_cfg_ = -1, sk_kc_ = 0, sk_wgcu_ = 0;
     long plane_ = 0, field_elems_ = 0;
     std::vector<Slab> slabs_;
     ncclComm_t comm_ = nullptr;
@@ -1970,6 +1996,19 @@ int sf_snapshot_read(sf_ctx* ctx, int index, void* host) {
         ctx->snap_err = f.msg;
         return f.code;
     } catch (const std::exception& e) {  // e.g. std::bad_alloc: nothing may cross the C ABI
+        ctx->snap_err = e.what();
+        return SF_ERR_INVALID;
+    }
+}
+int sf_snapshot_read_planes(sf_ctx* ctx, int index, int k_begin, int k_end, void* host) {
+    if (!ctx || !ctx->impl) return SF_ERR_INVALID;
+    try {
+        ctx->impl->snapshot_read_planes(index, k_begin, k_end, host);
+        return SF_OK;
+    } catch (const Failure& f) {
+        ctx->snap_err = f.msg;
+        return f.code;
+    } catch (const std::exception& e) {
         ctx->snap_err = e.what();
         return SF_ERR_INVALID;
     }

@@ -23,6 +23,7 @@
 //
 //   sf_driver [--n 64] [--steps 20] [--iters 20] [--dtype f32|f64] [--every 10] [--out DIR]
 //             [--binary] [--device 0] [--slabs 1] [--plumbing] [--quiet] [--sync-output] [--tracers 0]
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -53,7 +54,7 @@ static sf_ctx* g_ctx = nullptr;
 
 struct Options {
     int n = 64, steps = 20, iters = 20, every = 10, device = 0, slabs = 1, tracers = 0;
-    bool f64 = false, binary = false, plumbing = false, quiet = false, sync_output = false;
+    bool f64 = false, binary = false, plumbing = false, quiet = false, sync_output = false, loopback = false;
     std::string out = ".";
     int rank = 0, world = 1, local_rank = 0;
 };
@@ -64,24 +65,37 @@ static int env_int(const char* name, int dflt) {
 }
 
 // Single-node exchange of the 128-byte ncclUniqueId: rank 0 writes it (atomically, via rename), the others poll.
-static void share_nccl_id(const Options& o, unsigned char* id) {
-    char path[256], tmp[300];
-    snprintf(path, sizeof path, "/tmp/sf_ncclid_%d_%s.bin", env_int("MASTER_PORT", 29500),
+// The file name is unique per launch — it carries the pid of the launching agent (torch.distributed.run starts every
+// local rank as its child) besides the rendezvous port — so a file left by an earlier run can never be taken for
+// this run's; rank 0 removes a stale one before it publishes, and removes its own once sf_create has returned (the
+// communicator exists then, so every rank has read the id). SF_NCCL_ID_FILE names the file explicitly for launchers
+// whose ranks do not share a parent.
+static std::string nccl_id_path() {
+    if (const char* f = getenv("SF_NCCL_ID_FILE")) return f;
+    char path[256];
+    snprintf(path, sizeof path, "/tmp/sf_ncclid_%d_%ld_%s.bin", env_int("MASTER_PORT", 29500), (long)getppid(),
              getenv("TORCHELASTIC_RUN_ID") ? getenv("TORCHELASTIC_RUN_ID") : "run");
+    return path;
+}
+
+static void share_nccl_id(const Options& o, unsigned char* id) {
+    const std::string path = nccl_id_path();
     if (o.rank == 0) {
+        unlink(path.c_str());  // whatever is there is not ours
         if (sf_nccl_unique_id(id) != SF_OK) {
             fprintf(stderr, "Error: sf_nccl_unique_id failed\n");
             exit(1);
         }
-        snprintf(tmp, sizeof tmp, "%s.tmp%d", path, (int)getpid());
-        FILE* f = fopen(tmp, "wb");
-        if (!f || fwrite(id, 1, SF_NCCL_ID_BYTES, f) != SF_NCCL_ID_BYTES || fclose(f) != 0 || rename(tmp, path) != 0) {
-            fprintf(stderr, "Error: cannot publish the nccl id at %s\n", path);
+        const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
+        FILE* f = fopen(tmp.c_str(), "wb");
+        if (!f || fwrite(id, 1, SF_NCCL_ID_BYTES, f) != SF_NCCL_ID_BYTES || fclose(f) != 0 ||
+            rename(tmp.c_str(), path.c_str()) != 0) {
+            fprintf(stderr, "Error: cannot publish the nccl id at %s\n", path.c_str());
             exit(1);
         }
     } else {
-        for (int tries = 0; tries < 600; ++tries) {  // up to 60 s
-            FILE* f = fopen(path, "rb");
+        for (int tries = 0; tries < 1200; ++tries) {  // up to 120 s
+            FILE* f = fopen(path.c_str(), "rb");
             if (f) {
                 const size_t n = fread(id, 1, SF_NCCL_ID_BYTES, f);
                 fclose(f);
@@ -89,7 +103,7 @@ static void share_nccl_id(const Options& o, unsigned char* id) {
             }
             usleep(100000);
         }
-        fprintf(stderr, "Error: rank %d timed out waiting for %s\n", o.rank, path);
+        fprintf(stderr, "Error: rank %d timed out waiting for %s\n", o.rank, path.c_str());
         exit(1);
     }
 }
@@ -121,6 +135,11 @@ static Options parse(int argc, char** argv) {
         else if (s == "--quiet") o.quiet = true;
         else if (s == "--sync-output") o.sync_output = true;
         else if (s == "--tracers") o.tracers = atoi(next());
+        // rehearsal of ONE rank's share on a one-GPU box: the geometry, buffers, launches and frame file of rank
+        // --rank of --world, halo messages replaced by device-local copies (SF_FLAG_LOOPBACK_HALO), no communicator
+        else if (s == "--loopback") o.loopback = true;
+        else if (s == "--rank") o.rank = atoi(next());
+        else if (s == "--world") o.world = atoi(next());
         else {
             fprintf(stderr, "unknown option %s\n", s.c_str());
             exit(2);
@@ -134,39 +153,40 @@ static Options parse(int argc, char** argv) {
     return o;
 }
 
-// Analytic inputs of docs/SPEC.md §5, evaluated in double and rounded to T.
+// Analytic inputs of docs/SPEC.md §5, evaluated in double and rounded to T: ONE field on the global planes [kb, ke)
+// this process stores (never the whole (N+2)^3 array: at 1024^3 that is 4.3 GB per field and rank).
+// which: 0 u, 1 v, 2 w, 3 dens, 4 su, 5 sv, 6 sw, 7 sd.
 template <class T>
-struct Inputs {
-    std::vector<T> u, v, w, dens, su, sv, sw, sd;
-};
-
-template <class T>
-static Inputs<T> make_inputs(int N, double dt, bool plumbing) {
-    const size_t S = (size_t)N + 2, n = S * S * S;
-    Inputs<T> in;
-    for (auto* f : {&in.u, &in.v, &in.w, &in.dens, &in.su, &in.sv, &in.sw, &in.sd}) f->assign(n, T(0));
+static std::vector<T> make_input(int which, int N, int kb, int ke, double dt, bool plumbing) {
+    const size_t S = (size_t)N + 2;
+    std::vector<T> f(S * S * (size_t)(ke - kb), T(0));
     const double PI2 = 6.283185307179586476925286766559;
     const double A = 0.5 / (dt * N);
-    auto IX = [&](int i, int j, int k) { return (size_t)i + S * ((size_t)j + S * (size_t)k); };
-    if (!plumbing) {
-        for (int k = 1; k <= N; ++k)
+    auto at = [&](int i, int j, int k) -> T& { return f[(size_t)i + S * ((size_t)j + S * (size_t)(k - kb))]; };
+    if (!plumbing && (which == 0 || which == 1 || which == 3)) {
+        std::vector<double> sn(S), cs(S);
+        for (int i = 1; i <= N; ++i) {
+            sn[i] = std::sin(PI2 * (i - 0.5) / N);
+            cs[i] = std::cos(PI2 * (i - 0.5) / N);
+        }
+        for (int k = std::max(kb, 1); k < std::min(ke, N + 1); ++k)
             for (int j = 1; j <= N; ++j)
                 for (int i = 1; i <= N; ++i) {
-                    const double X = (i - 0.5) / N, Y = (j - 0.5) / N, Z = (k - 0.5) / N;
-                    in.u[IX(i, j, k)] = (T)(A * std::sin(PI2 * X) * std::cos(PI2 * Y));
-                    in.v[IX(i, j, k)] = (T)(-A * std::cos(PI2 * X) * std::sin(PI2 * Y));
-                    in.dens[IX(i, j, k)] =
-                        (T)(0.5 + 0.5 * std::sin(PI2 * X) * std::sin(PI2 * Y) * std::sin(PI2 * Z));
+                    if (which == 0) at(i, j, k) = (T)(A * sn[i] * cs[j]);
+                    if (which == 1) at(i, j, k) = (T)(-A * cs[i] * sn[j]);
+                    if (which == 3) at(i, j, k) = (T)(0.5 + 0.5 * sn[i] * sn[j] * sn[k]);
                 }
     }
     const int c = N / 2 > 0 ? N / 2 : 1;
-    in.sd[IX(c, c, c)] = T(100);
-    in.sv[IX(c, c, c)] = plumbing ? T(5) : (T)A;
-    return in;
+    if (c >= kb && c < ke) {
+        if (which == 7) at(c, c, c) = T(100);
+        if (which == 5) at(c, c, c) = plumbing ? T(5) : (T)A;
+    }
+    return f;
 }
 
-// One frame = the interior cells of global planes [kb, ke) (1-based k), density scalar + velocity vector, cell
-// centred. Single process: the whole cube as a regular mesh "anim_s<frame>.vtk". Several processes: each rank
+// One frame = the interior cells of global planes [kb, ke) (1-based k; the host arrays hold exactly those planes),
+// density scalar + velocity vector, cell centred. Single process: the whole cube as a regular mesh "anim_s<frame>.vtk". Several processes: each rank
 // writes its slab "anim_s_GPU<rank>_<frame>.vtk" as a rectilinear mesh whose z coordinates are its plane range.
 template <class T>
 static void write_frame(const Options& o, int frame, int kb, int ke, const std::vector<T>& dens,
@@ -179,7 +199,7 @@ static void write_frame(const Options& o, int frame, int kb, int ke, const std::
     for (int k = kb; k < ke; ++k)
         for (int j = 1; j <= N; ++j)
             for (int i = 1; i <= N; ++i, ++q) {
-                const size_t s = (size_t)i + S * ((size_t)j + S * (size_t)k);
+                const size_t s = (size_t)i + S * ((size_t)j + S * (size_t)(k - kb));  // buffers start at plane kb
                 d[q] = (float)dens[s];
                 vel[3 * q + 0] = (float)u[s];
                 vel[3 * q + 1] = (float)v[s];
@@ -215,12 +235,13 @@ static int run(const Options& o) {
     p.dt = dt;
     p.diff = diff;
     p.visc = visc;
-    p.device = o.world > 1 ? o.local_rank : o.device;
+    p.device = (o.world > 1 && !o.loopback) ? o.local_rank : o.device;
+    p.flags = o.loopback ? SF_FLAG_LOOPBACK_HALO : 0;
     p.nslabs_local = o.slabs;
     p.rank = o.rank;
     p.nranks = o.world;
     unsigned char nccl_id[SF_NCCL_ID_BYTES];
-    if (o.world > 1) {
+    if (o.world > 1 && !o.loopback) {
         share_nccl_id(o, nccl_id);
         p.nccl_id = nccl_id;
     }
@@ -230,6 +251,7 @@ static int run(const Options& o) {
                 __LINE__, __FILE__);
         exit(1);
     }
+    if (o.world > 1 && !o.loopback && o.rank == 0) unlink(nccl_id_path().c_str());  // every rank has joined the communicator
     const bool talk = (o.rank == 0);
     if (talk)
         std::cout << sf_version() << "  N=" << o.n << " K=" << o.iters << " dtype=" << (sizeof(T) == 4 ? "f32" : "f64")
@@ -237,22 +259,30 @@ static int run(const Options& o) {
     int own_kb = 1, own_ke = o.n + 1;
     SF_CHECK_RETURN(sf_owned_planes(g_ctx, &own_kb, &own_ke));
 
-    Inputs<T> in = make_inputs<T>(o.n, dt, o.plumbing);
-    SF_CHECK_RETURN(sf_upload(g_ctx, SF_U, in.u.data()));
-    SF_CHECK_RETURN(sf_upload(g_ctx, SF_V, in.v.data()));
-    SF_CHECK_RETURN(sf_upload(g_ctx, SF_W, in.w.data()));
-    SF_CHECK_RETURN(sf_upload(g_ctx, SF_DENS, in.dens.data()));
+    // inputs: only the planes this process stores, one field at a time (host memory per rank stays O(N^3 / ranks))
+    int st_kb = 0, st_ke = o.n + 2;
+    SF_CHECK_RETURN(sf_stored_planes(g_ctx, &st_kb, &st_ke));
+    {
+        const int slot[8] = {SF_U, SF_V, SF_W, SF_DENS, SF_USER0, SF_USER1, SF_USER2, SF_USER3};
+        for (int q = 0; q < 8; ++q) {
+            const std::vector<T> f = make_input<T>(q, o.n, st_kb, st_ke, dt, o.plumbing);
+            SF_CHECK_RETURN(sf_upload_planes(g_ctx, slot[q], st_kb, st_ke, f.data()));
+        }
+    }
     for (int f : {SF_U, SF_V, SF_W}) SF_CHECK_RETURN(sf_set_bnd(g_ctx, f + 1, f));
     SF_CHECK_RETURN(sf_set_bnd(g_ctx, 0, SF_DENS));
-    // sources stay resident in HBM and are re-injected every step
-    SF_CHECK_RETURN(sf_upload(g_ctx, SF_USER0, in.su.data()));
-    SF_CHECK_RETURN(sf_upload(g_ctx, SF_USER1, in.sv.data()));
-    SF_CHECK_RETURN(sf_upload(g_ctx, SF_USER2, in.sw.data()));
-    SF_CHECK_RETURN(sf_upload(g_ctx, SF_USER3, in.sd.data()));
+    // sources stay resident in HBM (SF_USER0..3) and are re-injected every step
     SF_CHECK_RETURN(sf_bind_sources(g_ctx, SF_USER0, SF_USER1, SF_USER2, SF_USER3));
 
-    const size_t n = ((size_t)o.n + 2) * ((size_t)o.n + 2) * ((size_t)o.n + 2);
-    std::vector<T> hd(n), hu(n), hv(n), hw(n);
+    // frame buffers: the planes this process owns, nothing else
+    const size_t n = ((size_t)o.n + 2) * ((size_t)o.n + 2) * (size_t)(own_ke - own_kb);
+    std::vector<T> hd, hu, hv, hw;
+    if (o.every > 0) {
+        hd.resize(n);
+        hu.resize(n);
+        hv.resize(n);
+        hw.resize(n);
+    }
 
     // tracers: a small lattice in the middle of the box, in grid-index coordinates (SPEC §6)
     std::vector<T> tpos, tdens, tspeed;
@@ -307,10 +337,10 @@ static int run(const Options& o) {
             if (ntr > 0) SF_CHECK_RETURN(sf_tracers_get(g_ctx, tpos.data(), tdens.data(), tspeed.data()));
             if (o.sync_output) {
                 SF_CHECK_RETURN(sf_sync(g_ctx));
-                SF_CHECK_RETURN(sf_download(g_ctx, SF_DENS, hd.data()));
-                SF_CHECK_RETURN(sf_download(g_ctx, SF_U, hu.data()));
-                SF_CHECK_RETURN(sf_download(g_ctx, SF_V, hv.data()));
-                SF_CHECK_RETURN(sf_download(g_ctx, SF_W, hw.data()));
+                SF_CHECK_RETURN(sf_download_planes(g_ctx, SF_DENS, own_kb, own_ke, hd.data()));
+                SF_CHECK_RETURN(sf_download_planes(g_ctx, SF_U, own_kb, own_ke, hu.data()));
+                SF_CHECK_RETURN(sf_download_planes(g_ctx, SF_V, own_kb, own_ke, hv.data()));
+                SF_CHECK_RETURN(sf_download_planes(g_ctx, SF_W, own_kb, own_ke, hw.data()));
                 write_frame<T>(o, frame, own_kb, own_ke, hd, hu, hv, hw);
                 if (ntr > 0) write_tracers(frame);
             } else {
@@ -319,7 +349,7 @@ static int run(const Options& o) {
                 writer = std::thread([&, frame]() {
                     T* dst[4] = {hd.data(), hu.data(), hv.data(), hw.data()};
                     for (int q = 0; q < 4; ++q)
-                        if (sf_snapshot_read(g_ctx, q, dst[q]) != SF_OK) {
+                        if (sf_snapshot_read_planes(g_ctx, q, own_kb, own_ke, dst[q]) != SF_OK) {
                             fprintf(stderr, "Error: snapshot read failed for frame %d\n", frame);
                             exit(1);
                         }

@@ -1062,7 +1062,8 @@ __device__ __forceinline__ void j2k_shells(__amdgpu_buffer_rsrc_t rm, __amdgpu_b
 // set_bnd between sweeps is applied in registers exactly as in jacobi2_kernel (i: sx*, j/k walls: sy*, sz* of the
 // adjacent interior value), so the result is bit-identical to S separate sweeps.
 // Mapping: a j-block holds V = NW*TJ - 2S output rows; the (j-block, vector) items are numbered in memory order and a
-// workgroup takes 64-2S consecutive ones in lanes S..63-S (the overlapped mapping of jacobi2_kernel, any row width).
+// workgroup takes P = 64 - 2*ceil(S/WL) consecutive ones in the middle lanes (the overlapped mapping of jacobi2_kernel,
+// any row width); the outer lanes only feed the shuffles.
 // (left + right) of a two-cell lane vector whose i-neighbours sit in the adjacent lanes: e0 = c1[lane-1] + c1,
 // e1 = c0 + c0[lane+1]. For float the lane shift rides on the add itself (v_add_f32 with a DPP source: two
 // instructions instead of two DPP moves, a packed add and their wait states). Same operands, same IEEE sums.
@@ -1337,7 +1338,10 @@ __device__ __forceinline__ void jsk_march(const Geom& g, SkShared<T, WL, S, TJ, 
 template <class T, int NF, int WL, bool NT, int S, int TJ, int NW, bool ISH>
 __global__ void __launch_bounds__(64 * NW, SF_SK_WAVES) jacobi_sk_kernel(Geom g, JacobiArgs<T, NF> A, int kb, int ke,
                                                                          SkMap m) {
-    constexpr int P = 64 - 2 * S;       // productive lanes of a wave
+    // Every sweep level loses one CELL of validity per side in i, so after S levels ceil(S / WL) lanes per side hold
+    // at least one invalid cell and only feed the shuffles
+    constexpr int F = (S + WL - 1) / WL;
+    constexpr int P = 64 - 2 * F;       // productive lanes of a wave
     constexpr int V = NW * TJ - 2 * S;  // output rows of a j-block
     static_assert(V > 0, "tile too small for the sweep depth");
     __shared__ SkShared<T, WL, S, TJ, NW> sh;
@@ -1360,8 +1364,8 @@ __global__ void __launch_bounds__(64 * NW, SF_SK_WAVES) jacobi_sk_kernel(Geom g,
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int total = m.njb * nvec;
-    int t = cb * P + lane - S;
-    const bool active = t >= 0 && t < total && lane >= S && lane < 64 - S;
+    int t = cb * P + lane - F;
+    const bool active = t >= 0 && t < total && lane >= F && lane < 64 - F;
     t = t < 0 ? 0 : (t >= total ? total - 1 : t);  // feeder / padding lanes run on valid addresses
     const int jb = nvec == 1 ? t : (int)__umulhi((unsigned)t, m.nvec_magic);
     const int vec = t - jb * nvec;
@@ -1409,7 +1413,7 @@ __global__ void __launch_bounds__(64 * NW, SF_SK_WAVES) jacobi_sk_kernel(Geom g,
     const int jb_hi = nvec == 1 ? thi : (int)__umulhi((unsigned)thi, m.nvec_magic);
     const bool jwall = jb_lo == 0 || (jb_hi + 1) * V + S >= N;  // a tile row (halo included) is j = 1 or j = N
     // ... and a row end (a lane, feeder lanes included, whose vector is the first or last of its row)? Uniform as well.
-    int flo = cb * P - S, fhi = cb * P + P - 1 + S;
+    int flo = cb * P - F, fhi = cb * P + P - 1 + F;
     flo = flo < 0 ? 0 : flo;
     fhi = fhi >= total ? total - 1 : fhi;
     const int fb_lo = nvec == 1 ? flo : (int)__umulhi((unsigned)flo, m.nvec_magic);

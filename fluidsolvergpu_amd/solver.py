@@ -32,7 +32,7 @@ ABI_SYMBOLS = (
     "dens_step", "sf_add_source", "sf_set_bnd", "sf_lin_solve", "sf_diffuse", "sf_advect", "sf_project",
     "sf_set_iters", "sf_set_coefficients", "sf_sync", "sf_last_error", "sf_timer_start", "sf_timer_stop",
     "sf_measure_copy_bandwidth", "sf_layout_info", "sf_schedule_info", "sf_lin_solve_launches", "sf_snapshot", "sf_snapshot_read",
-    "sf_tracers_set", "sf_tracers_advect", "sf_tracers_get", "sf_bind_sources", "sf_transport_info",
+    "sf_tracers_set", "sf_tracers_advect", "sf_tracers_get", "sf_bind_sources", "sf_transport_info", "sf_snapshot_read_planes",
 )
 
 
@@ -78,6 +78,7 @@ lib.sf_lin_solve_launches.argtypes = [_ctx, C.c_int]
 lib.sf_bind_sources.argtypes = [_ctx, C.c_int, C.c_int, C.c_int, C.c_int]
 lib.sf_snapshot.argtypes = [_ctx, C.POINTER(C.c_int), C.c_int]
 lib.sf_snapshot_read.argtypes = [_ctx, C.c_int, C.c_void_p]
+lib.sf_snapshot_read_planes.argtypes = [_ctx, C.c_int, C.c_int, C.c_int, C.c_void_p]
 lib.sf_tracers_set.argtypes = [_ctx, C.c_int, C.c_void_p]
 lib.sf_tracers_advect.argtypes = [_ctx]
 lib.sf_tracers_get.argtypes = [_ctx, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -257,6 +258,13 @@ class FluidSolver:
         rc = lib.sf_snapshot_read(self._h, int(index), out.ctypes.data_as(C.c_void_p))
         if rc != SF_OK:
             raise SfError(rc, "sf_snapshot_read failed")
+        return out
+
+    def snapshot_read_planes(self, index, k_begin, k_end):
+        out = np.zeros((k_end - k_begin, self.N + 2, self.N + 2), self.np_dtype)
+        rc = lib.sf_snapshot_read_planes(self._h, int(index), int(k_begin), int(k_end), out.ctypes.data_as(C.c_void_p))
+        if rc != SF_OK:
+            raise SfError(rc, "sf_snapshot_read_planes failed")
         return out
 
     def tracers_set(self, xyz):

@@ -142,6 +142,9 @@ int sf_project(sf_ctx* ctx, int u, int v, int w, int p, int div);
  * thread while the owner keeps stepping; do not call sf_snapshot again before all reads have returned. */
 int sf_snapshot(sf_ctx* ctx, const int* fields, int nfields);
 int sf_snapshot_read(sf_ctx* ctx, int index, void* host);
+/* The same for global planes [k_begin, k_end) only; `host` holds exactly those planes, dense (N+2)^2 each (what a
+ * rank of a decomposed run needs for its own frame file: solver-unidyn.cu:484-490 writes one file per device). */
+int sf_snapshot_read_planes(sf_ctx* ctx, int index, int k_begin, int k_end, void* host);
 
 /* Tracer particles (docs/SPEC.md §6; feeds the write_point_mesh call of solver-unidyn.cu:487). Positions are
  * x y z triples in grid-index coordinates, element type = the context's dtype. Single-slab contexts only.

@@ -41,6 +41,16 @@ def assert_same(got, want, what):
 
 SIZES = [1, 2, 3, 5, 8, 13, 16, 31, 34]
 DTYPES = [np.float32, np.float64]
+
+
+@pytest.fixture(params=["auto", "marching"])
+def march_mode(request, monkeypatch):
+    """The k-marching S-sweep kernel only takes grids of a few million cells by default (smaller ones do not fill the
+    chip with its 512-thread workgroups); "marching" lowers that threshold to zero so that the small, wall-dominated,
+    odd-sized cases of these tests run through it as well."""
+    if request.param == "marching":
+        monkeypatch.setenv("SF_MARCH_MINCELLS_K", "0")
+    return request.param
 # Halo transport between the logical slabs of one context: the device-local copy kernel, or a real single-rank RCCL
 # communicator with grouped ncclSend / ncclRecv to self (SF_FLAG_RCCL_SELF: the calls, streams and fences of the
 # multi-process exchange, executed on the one GPU a test box has).
@@ -104,7 +114,7 @@ def test_set_bnd(N, b, dtype):
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "f64"])
 @pytest.mark.parametrize("b", [0, 1, 2, 3])
 @pytest.mark.parametrize("N,K", [(1, 3), (2, 2), (3, 5), (8, 4), (13, 3), (16, 1), (31, 6), (34, 7), (64, 3)])
-def test_lin_solve(N, K, b, dtype):
+def test_lin_solve(N, K, b, dtype, march_mode):
     f = rand_fields(N, dtype, 4)
     a, c = 0.37, 1 + 6 * 0.37
     with make(N, dtype) as fs:
@@ -121,7 +131,7 @@ def test_lin_solve(N, K, b, dtype):
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "f64"])
 @pytest.mark.parametrize("N,K,b", [(100, 4, 1), (108, 5, 2), (20, 6, 3), (324, 4, 0), (408, 2, 1), (516, 2, 3)])
-def test_lin_solve_rows_that_straddle_waves(N, K, b, dtype):
+def test_lin_solve_rows_that_straddle_waves(N, K, b, dtype, march_mode):
     """Row widths that are not a power of two, and rows wider than two waves (up to 258 vectors here): the fused
     kernel's overlapped mapping packs the (row pair, vector) items of a plane pair into 60-lane windows, so rows
     start and end anywhere inside a wave."""
@@ -191,7 +201,7 @@ def test_advect_lds_path(N, b, mode, dtype, monkeypatch):
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "f64"])
 @pytest.mark.parametrize("N,K", [(1, 2), (3, 3), (8, 4), (17, 5), (32, 6)])
-def test_project(N, K, dtype):
+def test_project(N, K, dtype, march_mode):
     f = rand_fields(N, dtype, 7)
     with make(N, dtype, K=K) as fs:
         for n in ("u", "v", "w", "u0", "v0"):
@@ -205,7 +215,7 @@ def test_project(N, K, dtype):
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "f64"])
 @pytest.mark.parametrize("N,K,steps", [(2, 3, 2), (7, 4, 2), (16, 5, 3), (32, 10, 1), (34, 4, 2), (64, 6, 1)])
-def test_full_steps(N, K, steps, dtype):
+def test_full_steps(N, K, steps, dtype, march_mode):
     f = rand_fields(N, dtype, 8)
     src = {n: f[n].copy() for n in ("u0", "v0", "w0", "dens0")}
     with make(N, dtype, K=K) as fs:
@@ -260,7 +270,7 @@ def test_slabs_full_step_bit_identical(N, P, transport, dtype):
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "f64"])
 @pytest.mark.parametrize("transport", TRANSPORTS)
 @pytest.mark.parametrize("N,P,K,steps", [(64, 2, 7, 2), (64, 8, 6, 1), (48, 4, 4, 2), (128, 4, 5, 1)])
-def test_slabs_fused_pairs_two_ghost_planes(N, P, K, steps, transport, dtype):
+def test_slabs_fused_pairs_two_ghost_planes(N, P, K, steps, transport, dtype, march_mode):
     """N % vector width == 0 and >= 2 planes per slab: sweep pairs are fused across slab boundaries (two ghost
     planes, one exchange per pair, div recomputed on the first ghost plane). Must still equal the oracle."""
     f = small_velocity(rand_fields(N, dtype, 21), N, dtype)
@@ -568,6 +578,7 @@ def test_snapshot_is_a_consistent_async_copy(P):
         def reader():
             for q, n in enumerate(("dens", "u", "v", "w")):
                 result[n] = fs.snapshot_read(q)
+            result["dens[5:19]"] = fs.snapshot_read_planes(0, 5, 19)  # a plane range across slab boundaries
 
         th = threading.Thread(target=reader)
         th.start()
@@ -579,6 +590,7 @@ def test_snapshot_is_a_consistent_async_copy(P):
     O.step(N, f, dtype(DT), dtype(DIFF), dtype(VISC), K)
     for n in ("dens", "u", "v", "w"):
         assert_same(result[n], f[n], f"snapshot {n}")
+    assert_same(result["dens[5:19]"], f["dens"][5:19], "snapshot plane range")
 
 
 @pytest.mark.parametrize("fuse", ["1", "0"])
@@ -588,7 +600,7 @@ def test_snapshot_is_a_consistent_async_copy(P):
                                           (6, 1, np.float32, 1), (256, 4, np.float32, 1), (64, 6, np.float32, 4),
                                           (128, 20, np.float32, 2), (160, 6, np.float32, 4), (64, 5, np.float64, 2),
                                           (16, 4, np.float32, 8), (16, 4, np.float32, 4)])
-def test_bound_sources(N, K, dtype, P, fuse, monkeypatch):
+def test_bound_sources(N, K, dtype, P, fuse, monkeypatch, march_mode):
     """sf_bind_sources == copying the user slots into u0/v0/w0/dens0 before every step, bit for bit — with add_source
     folded into the first sweep pair of diffuse (SF_FUSE_SRC=1, single slab) and as a separate pass."""
     monkeypatch.setenv("SF_FUSE_SRC", fuse)
@@ -796,6 +808,52 @@ def test_driver_frame_equals_config1_golden(tmp_path):
         assert hashlib.sha256(data).hexdigest() == gold[key]["sha256"]
 
 
+def test_driver_slab_frames_equal_the_single_slab_frame(tmp_path):
+    """The C++ driver with several logical slabs (per-slab inputs through sf_upload_planes, frame buffers sized to the
+    owned planes, plane-ranged snapshot reads) writes the same bytes as with one slab, synchronously and through the
+    writer thread."""
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "fluidsolvergpu_amd", "sf_driver")
+    frames = {}
+    for tag, extra in (("one", []), ("four", ["--slabs", "4"]), ("four-sync", ["--slabs", "4", "--sync-output"])):
+        out_dir = tmp_path / tag
+        cmd = [exe, "--n", "48", "--iters", "6", "--steps", "3", "--every", "2", "--binary", "--quiet", "--out",
+               str(out_dir)] + extra
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stdout + out.stderr
+        frames[tag] = [open(out_dir / f"anim_s{q}.vtk", "rb").read() for q in (0, 1)]
+    assert frames["four"] == frames["one"] and frames["four-sync"] == frames["one"]
+
+
+def test_driver_rank_share_of_config4_fits_in_host_memory(tmp_path):
+    """One rank's share of BASELINE.json configs[3] (1024^3 over 8 ranks) through the C++ driver: rank 3 of 8 in
+    loopback mode on the one GPU (same slab, buffers, launches and frame file as in the eight-rank run; halo messages
+    are local copies). The driver must hold only its own planes on the host: peak resident memory of the process
+    below 8 GB (it was ~52 GB per rank when every rank materialised the global arrays), and the rectilinear slab
+    frame must have the size of 128 planes."""
+    import os
+    import resource
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "fluidsolvergpu_amd", "sf_driver")
+    before = resource.getrusage(resource.RUSAGE_CHILDREN).ru_maxrss
+    cmd = [exe, "--n", "1024", "--iters", "4", "--steps", "1", "--every", "1", "--binary", "--quiet", "--loopback",
+           "--rank", "3", "--world", "8", "--out", str(tmp_path)]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    peak_kb = resource.getrusage(resource.RUSAGE_CHILDREN).ru_maxrss
+    assert peak_kb >= before
+    assert peak_kb < 8 * 1024 * 1024, f"driver peak RSS {peak_kb / 1048576:.1f} GiB"
+    size = os.path.getsize(tmp_path / "anim_s_GPU3_0.vtk")
+    cells = 1024 * 1024 * 128
+    assert cells * 16 < size < cells * 16 + 20000  # density + 3 velocity components, 4 bytes each, plus headers
+    os.remove(tmp_path / "anim_s_GPU3_0.vtk")
+
+
 def _random_cases(n, seed=1234):
     rng = np.random.RandomState(seed)
     out = []
@@ -811,7 +869,7 @@ def _random_cases(n, seed=1234):
 
 
 @pytest.mark.parametrize("case", _random_cases(36), ids=lambda c: f"N{c[0]}-P{c[1]}-K{c[2]}-s{c[3]}-{'f32' if c[4] == np.float32 else 'f64'}")
-def test_randomised_full_steps(case):
+def test_randomised_full_steps(case, march_mode):
     """Seeded random sweep over grid size, slab count, iteration count (incl. 0 and odd), steps and dtype."""
     N, P, K, steps, dtype, seed = case
     f = small_velocity(rand_fields(N, dtype, seed), N, dtype)

@@ -1,0 +1,60 @@
+"""The SF_* switches that change kernels or launch schedules, each run against the CPU oracle (bit for bit) inside
+`pytest -m gpu`, so the driver's GPU run covers more than the defaults (tools/switch_matrix.sh repeats a larger
+subset of the suite under every documented switch). libsfgpu.so reads the switches at context creation."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from test_parity_gpu import DT, DIFF, VISC, NAMES, assert_same, make, rand_fields, small_velocity
+
+pytestmark = pytest.mark.gpu
+
+SWITCHES = [
+    {},                             # defaults (three-sweep marching kernel on one slab, two-sweep on slab interiors)
+    {"SF_MARCH": "0"},              # register-blocked pair kernel everywhere
+    {"SF_SK_S": "2"},               # marching kernel limited to two sweeps per pass
+    {"SF_FUSE2": "0"},              # single sweeps, one ghost plane
+    {"SF_OVL": "0"}, {"SF_OVL": "2"},
+    {"SF_TRAP": "0"}, {"SF_TRAP": "2"}, {"SF_TRAP": "5"},
+    {"SF_HALO_STREAM": "1"}, {"SF_HALO_STREAM": "2"},
+    {"SF_SPLIT_FIELDS": "0"}, {"SF_SPLIT_FIELDS": "2"},
+    {"SF_GHOST": "1"},
+    {"SF_FUSE_SRC": "0"}, {"SF_ZERO_SKIP": "0"}, {"SF_SPLIT": "0"},
+    {"SF_MARCH": "0", "SF_TRAP": "3", "SF_HALO_STREAM": "2", "SF_SPLIT_FIELDS": "0"},
+]
+
+
+def run_case(N, P, K, steps, transport="copy"):
+    dtype = np.float32
+    f = small_velocity(rand_fields(N, dtype, 300 + N + P), N, dtype)
+    src = {n: f[n].copy() for n in ("u0", "v0", "w0", "dens0")}
+    kw = {"nslabs_local": P}
+    if transport == "rccl-self" and P >= 2:
+        kw["flags"] = 2
+    with make(N, dtype, K=K, **kw) as fs:
+        for n in NAMES:
+            fs.upload(n, f[n])
+        for slot, n in (("user0", "u0"), ("user1", "v0"), ("user2", "w0"), ("user3", "dens0")):
+            fs.upload(slot, src[n])
+        fs.bind_sources("user0", "user1", "user2", "user3")
+        for _ in range(steps):
+            fs.vel_step()
+            fs.dens_step()
+        fs.sync()
+        got = {n: fs.download(n) for n in ("u", "v", "w", "dens")}
+    for _ in range(steps):
+        for n in src:
+            f[n][...] = src[n]
+        O.step(N, f, dtype(DT), dtype(DIFF), dtype(VISC), K)
+    return got, f
+
+
+@pytest.mark.parametrize("env", SWITCHES, ids=lambda e: ",".join(f"{k[3:]}={v}" for k, v in e.items()) or "defaults")
+def test_switch_settings_against_the_oracle(env, monkeypatch):
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    monkeypatch.setenv("SF_MARCH_MINCELLS_K", "100")  # let the marching kernel take these small grids too
+    for N, P, K, steps, transport in ((64, 1, 7, 2, "copy"), (64, 4, 6, 1, "copy"), (96, 2, 5, 1, "rccl-self")):
+        got, want = run_case(N, P, K, steps, transport)
+        for n in got:
+            assert_same(got[n], want[n], f"{env} N={N} P={P} K={K} {transport}: {n}")
