@@ -54,7 +54,8 @@ def parse():
                     help="N > 1: steps of the same grid timed on rank 0's GPU alone afterwards (0 = skip)")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
-    ap.add_argument("--roofline-n", type=int, default=512, help="also time the lin_solve sweep at this size")
+    ap.add_argument("--roofline-n", type=int, default=512,
+                    help="grid of the HBM roofline entry (-1: skip the roofline legs, for quick config runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--local-slabs", type=int, default=1,
@@ -350,6 +351,12 @@ def main():
             return e
 
         hbm_n = args.roofline_n if args.roofline_n else 512
+        if hbm_n < 0:
+            print(json.dumps(out), flush=True)
+            if dist is not None:
+                dist.barrier()
+                dist.destroy_process_group()
+            return
         out["roofline"] = roofline_entry(hbm_n)
         out["roofline"]["note"] = (f"{hbm_n}^3: x, x0 and x' of the solve (3 x {float(hbm_n) ** 3 * wsize / 1e6:.0f} MB) are far "
                                    "beyond the 256 MiB Infinity Cache, so this is an HBM measurement. algorithmic bytes = 3 "
