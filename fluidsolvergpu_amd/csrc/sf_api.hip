@@ -168,7 +168,17 @@ public:
         // and exchange one plane per sweep
         const bool fusable = env_int("SF_FUSE2", 1) != 0 && env_int("SF_JACOBI", 2) != 0 && N_ % W == 0 &&
                              N_ / W <= env_int("SF_FUSE_MAXVEC", 512);
-        G_ = (P_ > 1 && nzl_ >= 2 && fusable && env_int("SF_GHOST", 2) >= 2) ? 2 : 1;
+        G_ = (P_ > 1 && nzl_ >= 2 && fusable && env_int("SF_GHOST", 3) >= 2) ? 2 : 1;
+        // three ghost planes where the three-sweep marching kernel will run on the slab interiors (one exchange per
+        // three sweeps): the interior launch [G+3, G+nzl-3) must be long and large enough for that kernel
+        {
+            const long min_cells = (long)env_int("SF_MARCH_MINCELLS_K", 6000) * 1000L;
+            const int interior = nzl_ - 6;
+            if (G_ == 2 && env_int("SF_GHOST", 3) >= 3 && env_int("SF_MARCH", 1) != 0 && env_int("SF_SK_S", 3) >= 3 &&
+                env_int("SF_SPLIT", 1) != 0 && interior >= env_int("SF_MARCH_MINP", 12) &&
+                (long)N_ * N_ * interior >= min_cells)
+                G_ = 3;
+        }
         nplanes_ = nzl_ + 2 * G_;
         field_elems_ = plane_ * nplanes_ + 256;  // slack so whole-vector accesses never leave the buffer
         field_elems_ = (field_elems_ + W - 1) / W * W;
@@ -270,6 +280,7 @@ public:
         march_k_ = env_int("SF_MARCH", 1);  // 0: the register-blocked pair kernel everywhere
         march_min_planes_ = env_int("SF_MARCH_MINP", 12);
         march_min_cells_ = (long)env_int("SF_MARCH_MINCELLS_K", 6000) * 1000L;  // ~182^3
+        sk2_min_cells_ = std::max(march_min_cells_ == 0 ? 0L : 60000000L, march_min_cells_);  // ~390^3
         sk_s_ = env_int("SF_SK_S", 3);
         sk_cfg_ = env_int("SF_SK_CFG", -1);  // tile shape: -1 automatic, 0..3 see SF_SK_CFGS
         sk_kc_ = env_int("SF_SK_KC", 0);
@@ -283,7 +294,7 @@ public:
     // the shallower one unless the deeper is 3 % faster. Every rank runs the same sequence of exchanges whatever it
     // picks (the depth only moves planes between this rank's own two launches), so ranks may differ in their choice.
     void tune_schedule() {
-        if (!(G_ == 2 && can_fuse2()) || nzl_ <= 2 * (G_ + 2) + 2) return;
+        if (!(G_ >= 2 && can_fuse2()) || nzl_ <= 2 * (G_ + 2) + 2) return;
         const int x[1] = {SF_DENS}, x0[1] = {SF_DENS0}, b0[1] = {0};
         const T a = T(0.25), c = T(1) + T(6) * a;
         auto drain = [&] {
@@ -1314,7 +1325,7 @@ private:
     // vector width and the grid is not decomposed (a second ghost plane would be needed).
     // (measured against single sweeps: +20 % at 512^3, +35 % at 256^3, +11 % at 1024^3 fp32, +15 % at 512^3 fp64)
     bool can_fuse2() const {
-        return fuse2_ && (P_ == 1 || G_ == 2) && N_ % W == 0 && N_ / W <= fuse_maxvec_ && jacobi_mode_ != 0;
+        return fuse2_ && (P_ == 1 || G_ >= 2) && N_ % W == 0 && N_ / W <= fuse_maxvec_ && jacobi_mode_ != 0;
     }
 
     template <int NF>
@@ -1441,8 +1452,11 @@ private:
 
     // S fused sweeps with LDS halo exchange (sfk::jacobi_sk_kernel). Same eligibility as the two-sweep marching kernel;
     // three sweeps only on an undecomposed grid (a slab boundary would need three ghost planes).
-    bool can_sk(int nplanes, bool first) const { return can_march_k(nplanes, first); }
-    int sk_max_sweeps() const { return (march_k_ != 0 && P_ == 1) ? std::min(sk_s_, 3) : 2; }
+    // (two-sweep launches — slab interiors with two ghost planes, remainders — only pay on large grids: at 256^3 the
+    // register-blocked pair kernel takes 49 us, the marching kernel 67; at 512^3 437 against 365)
+    bool can_sk(int nplanes, bool first, int sweeps = 3) const {
+        return can_march_k(nplanes, first) && (sweeps >= 3 || (long)N_ * N_ * nplanes >= sk2_min_cells_);
+    }
 
     int sk_chunks(int ncb, int np, int S) const {
         const int max_chunks = std::max(1, np / 8);
@@ -1472,14 +1486,18 @@ private:
         m.nvec_magic = nvec > 1 ? 0xFFFFFFFFu / (unsigned)nvec + 1u : 0u;
         const int np = ke - kb;
         int nchunk;
-        if (sk_kc_ > 0) {
+        if (split_ != INT_MAX) {
+            // boundary launch of a decomposed grid: the first and the last `split_` interior planes as two chunks
+            nchunk = 2;
+            m.gap = gap_;
+        } else if (sk_kc_ > 0) {
             nchunk = ceil_div(np, sk_kc_);
         } else {
             // The kernel is bound by the bytes a CU can request per unit time, so workgroups that share a CU share its
             // rate: time ~ (workgroups per CU, rounded up) x (steps per chunk: kc + 2S-2, plus start-up).
             nchunk = sk_chunks(m.ncb, np, S);
         }
-        m.kc = ceil_div(np, nchunk);
+        m.kc = split_ != INT_MAX ? split_ : ceil_div(np, nchunk);
         nchunk = ceil_div(np, m.kc);
         const dim3 nb(8u, (unsigned)m.band, (unsigned)nchunk);
         if (last)
@@ -1548,7 +1566,7 @@ private:
         const bool nt = nt_mode_ == 1 ||
                         (nt_mode_ == 2 && (size_t)field_elems_ * sizeof(T) * 3 * NF > ((size_t)384 << 20));
         if constexpr (!SRC) {
-            if (can_sk(ke - kb, first)) {
+            if (can_sk(ke - kb, first, 2)) {
                 launch_sk<NF, 2>(sl, A, kb, ke, last);
                 return;
             }
@@ -1575,13 +1593,23 @@ private:
     // Sweeps fused into the launch that starts at iteration `it` of a K-sweep solve: 3 where the S-sweep kernel is in
     // use (never the first pass of a solve, whose iterate is caller data / zero / a source; a remainder of four goes
     // as 2 + 2), else 2 where pairs can be fused, else 1.
-    int sweeps_in_launch(int it, int K, bool continued) const {
+    int sweeps_in_launch(int it, int K, bool continued, int extra = 0) const {
         const bool pair = can_fuse2() && it + 2 <= K;
         const int left = K - it;
-        const bool triple = pair && (it > 0 || continued) && sk_max_sweeps() >= 3 && left >= 3 && left != 4 &&
-                            can_sk(nzl_, false);
+        bool triple = pair && (it > 0 || continued) && march_k_ != 0 && sk_s_ >= 3 && left >= 3 && left != 4;
+        if (triple && P_ == 1) triple = can_sk(nzl_, false);
+        if (triple && P_ > 1) {
+            // decomposed: three ghost planes, the two-stream schedule, and an interior launch [G+3+extra, ...) the
+            // marching kernel takes (the boundary launch always goes through it: there is no other three-sweep kernel)
+            const int interior = nzl_ - 2 * (3 + extra);
+            triple = G_ == 3 && split_enabled_ && interior >= march_min_planes_ &&
+                     (long)N_ * N_ * interior >= march_min_cells_;
+        }
         return triple ? 3 : (pair ? 2 : 1);
     }
+    // boundary depth of a two-sweep launch: the register-blocked pair kernel works on plane pairs, and a plane block
+    // must not straddle the split of a boundary launch, so with three ghost planes it takes four planes per side
+    int pair_depth() const { return G_ == 3 ? 4 : 2; }
 
     // K Jacobi sweeps on NF fields at once; scratch buffers are swapped into the slots.
     template <int NF>
@@ -1615,17 +1643,32 @@ private:
         // compute stream, while boundary launch j (planes [G, G+2+2j), on its own stream, after interior j-1 and halo
         // j-1) feeds the halo exchange. Every trap_m_ pairs the interior snaps back and waits for the boundary once.
         // Same arithmetic on every plane whichever launch computes it: results do not change.
-        int tj = 0;
+        // With S sweeps per launch the growth is S planes per side: if interior launch j-1 started D planes into the
+        // slab, launch j starts D + S_j planes in (S_j = its sweeps), so it reads only what launch j-1 wrote; its
+        // boundary launch takes those D + S_j planes per side.
+        int tj = 0, dprev = 0;
         int it = 0;
         while (it < K) {
             const bool pair = can_fuse2() && it + 2 <= K;
             // three sweeps per pass where the S-sweep kernel is in use (never the first pass of a solve, whose iterate
             // is caller data; a remainder of four goes as 2 + 2)
-            const int step = sweeps_in_launch(it, K, continued);
-            const bool triple = step == 3;
+            const int step = sweeps_in_launch(it, K, continued, 0);
             x_is_zero_ = x_zero && it == 0 && pair;  // the first fused pair then loads no x at all
-            if (!pair || trap_m_ <= 1 || tj >= trap_m_ || nzl_ <= 2 * (G_ + 2 * tj) + 2) tj = 0;
-            trap_extra_ = (pair && P_ > 1 && G_ == 2) ? 2 * tj : 0;
+            const int depth0 = std::max(step == 2 ? pair_depth() : step, G_);  // boundary depth without growth
+            int extra = 0;
+            {
+                // does this launch continue the trapezoid block?
+                const int d = dprev + step;  // where its interior launch would start
+                bool cont = pair && P_ > 1 && G_ >= 2 && trap_m_ > 1 && tj > 0 && tj < trap_m_ && d >= depth0 &&
+                            nzl_ > 2 * d + 2;
+                if (cont && step == 3 && sweeps_in_launch(it, K, continued, d - depth0) != 3) cont = false;
+                if (cont && step == 2 && (d & 1)) cont = false;  // plane pairs: even boundary depth
+                if (!cont) tj = 0;
+                extra = cont ? d - depth0 : 0;
+                dprev = depth0 + extra;
+            }
+            const bool triple = step == 3;
+            trap_extra_ = extra;
             ++tj;
             for_planes([&](Slab& sl, int kb, int ke) {
                 sfk::JacobiArgs<T, NF> A;
@@ -1643,7 +1686,7 @@ private:
                     launch_jacobi2<NF>(sl, A, kb, ke, it == 0 && !continued, it + step == K);
                 else
                     launch_jacobi<NF>(sl, A, kb, ke, it == 0 && !continued, it + step == K);
-            }, step, jacobi_mode_ != 0);
+            }, step == 2 ? pair_depth() : step, jacobi_mode_ != 0);
             // the new iterate becomes the field; the old buffer becomes scratch
             for (Slab& sl : slabs_)
                 for (int f = 0; f < NF; ++f) std::swap(sl.field[x[f]], sl.scratch[f]);
@@ -1700,13 +1743,14 @@ private:
             A.inv = inv;
             A.dt = dt_;
             launch_jacobi2<NF, true>(sl, A, kb, ke, true, K == 2);
-        }, 2, true);
+        }, pair_depth(), true);
         if (P_ > 1) {
-            // right-hand side on the ghost planes G-1 and G+nzl. It reads ghost planes of x, so it must follow the
+            // right-hand side on the G-1 ghost planes next to the slab on either side (an S-sweep launch evaluates its
+            // first S-1 levels there and needs x0 for them). It reads ghost planes of x, so it must follow the
             // last halo: on the boundary stream when for_planes ran its two-stream schedule (bs waits for every halo
             // and the next boundary launch follows in stream order), on the compute stream otherwise (for_planes
             // has just joined it)
-            const bool two = split_enabled_ && nzl_ > 2 * std::max(2, G_);
+            const bool two = split_enabled_ && nzl_ > 2 * std::max(pair_depth(), G_);
             for (Slab& sl : slabs_) {
                 sfk::RhsPlanesArgs<T, NF> R;
                 for (int f = 0; f < NF; ++f) {
@@ -1715,9 +1759,9 @@ private:
                     R.s[f] = sl.field[src[f]];
                 }
                 R.dt = dt_;
-                R.off[0] = (long)(G_ - 1) * plane_;
-                R.off[1] = (long)(G_ + nzl_) * plane_;
-                R.nvec = plane_ / W;
+                R.off[0] = (long)1 * plane_;  // planes 1 .. G-1
+                R.off[1] = (long)(G_ + nzl_) * plane_;  // planes G+nzl .. G+nzl+G-2
+                R.nvec = (long)(G_ - 1) * plane_ / W;
                 hipLaunchKernelGGL((sfk::rhs_planes_kernel<T, NF>), dim3((unsigned)ceil_div(R.nvec, 256L), 2), dim3(256), 0,
                                    two ? sl.bs : sl.cs, R);
             }
@@ -1830,7 +1874,7 @@ private:
     bool ishell_skip_ = true, advect_lds_ = false, zero_skip_ = true, x_is_zero_ = false, fuse_src_ = true;
     int fuse2_ = 1, kc2_ = 32;
     int march_k_ = 1, march_min_planes_ = 12;
-    long march_min_cells_ = 6000000;
+    long march_min_cells_ = 6000000, sk2_min_cells_ = 60000000;
     int sk_s_ = 3, sk_cfg_ = -1, sk_kc_ = 0, sk_wgcu_ = 0;
     long plane_ = 0, field_elems_ = 0;
     std::vector<Slab> slabs_;

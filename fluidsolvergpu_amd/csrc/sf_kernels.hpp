@@ -1082,6 +1082,7 @@ struct SkMap {
     int kc;     // output planes per chunk
     int njb;    // j-blocks
     unsigned nvec_magic;
+    int gap;    // boundary launch of a decomposed grid: chunk 1 starts `gap` planes after the end of chunk 0
 };
 
 template <class T, int WL, int S, int TJ, int NW>
@@ -1371,8 +1372,9 @@ __global__ void __launch_bounds__(64 * NW, SF_SK_WAVES) jacobi_sk_kernel(Geom g,
     const int vec = t - jb * nvec;
     const int i0 = 1 + WL * vec;
     const int jrow0 = jb * V + 1 - S + wave * TJ;  // j of this lane's row 0 (may lie outside [0, N+1]: clamped below)
-    const int k0 = kb + chunk * m.kc;
-    const int k1 = (k0 + m.kc < ke) ? k0 + m.kc : ke;
+    const int shift = chunk > 0 ? m.gap : 0;  // (gap != 0 only for the two-chunk boundary launch)
+    const int k0 = kb + chunk * m.kc + shift;
+    const int k1 = ((kb + chunk * m.kc + m.kc < ke) ? kb + chunk * m.kc + m.kc : ke) + shift;
 
     const T a = A.a, inv = A.inv;
     const T* __restrict__ x = A.x[0];

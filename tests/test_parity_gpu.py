@@ -329,7 +329,7 @@ def test_slabs_stress_against_single_slab(N, P, K, prio, transport, monkeypatch)
 @pytest.mark.parametrize("N,P,K,trap", [(128, 2, 20, "5"), (128, 4, 20, "3"), (160, 4, 12, "10"), (320, 2, 20, "5"),
                                         (128, 2, 20, "0"), (64, 2, 9, "4")])
 @pytest.mark.parametrize("transport", TRANSPORTS)
-def test_slabs_trapezoid_schedule(N, P, K, trap, transport, monkeypatch):
+def test_slabs_trapezoid_schedule(N, P, K, trap, transport, monkeypatch, march_mode):
     """lin_solve on a decomposed grid: the boundary launch grows by two planes per pair so that consecutive interior
     launches need no cross-stream wait (SF_TRAP pairs per block; 0 = off). Long solves (several blocks, a resync in
     between, odd K, a row width that takes the overlapped mapping) must equal the single-slab GPU run bit for bit."""
@@ -355,7 +355,7 @@ def test_slabs_trapezoid_schedule(N, P, K, trap, transport, monkeypatch):
 
 @pytest.mark.parametrize("transport", TRANSPORTS)
 @pytest.mark.parametrize("N,P,K", [(128, 2, 8), (96, 4, 5), (64, 8, 4), (160, 2, 20)])
-def test_slabs_halo_on_the_boundary_stream(N, P, K, transport, monkeypatch):
+def test_slabs_halo_on_the_boundary_stream(N, P, K, transport, monkeypatch, march_mode):
     """One slab per process issues its halo messages on the boundary stream (no cross-stream hand-over in the chain
     boundary launch -> message -> next boundary launch). SF_HALO_STREAM=2 applies the same stream sharing to the
     logical slabs of one process, where the result can be checked: bit-identical to the single-slab run, with bound

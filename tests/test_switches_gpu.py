@@ -18,7 +18,7 @@ SWITCHES = [
     {"SF_TRAP": "0"}, {"SF_TRAP": "2"}, {"SF_TRAP": "5"},
     {"SF_HALO_STREAM": "1"}, {"SF_HALO_STREAM": "2"},
     {"SF_SPLIT_FIELDS": "0"}, {"SF_SPLIT_FIELDS": "2"},
-    {"SF_GHOST": "1"},
+    {"SF_GHOST": "1"}, {"SF_GHOST": "2"},
     {"SF_FUSE_SRC": "0"}, {"SF_ZERO_SKIP": "0"}, {"SF_SPLIT": "0"},
     {"SF_MARCH": "0", "SF_TRAP": "3", "SF_HALO_STREAM": "2", "SF_SPLIT_FIELDS": "0"},
 ]
@@ -54,7 +54,8 @@ def test_switch_settings_against_the_oracle(env, monkeypatch):
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     monkeypatch.setenv("SF_MARCH_MINCELLS_K", "100")  # let the marching kernel take these small grids too
-    for N, P, K, steps, transport in ((64, 1, 7, 2, "copy"), (64, 4, 6, 1, "copy"), (96, 2, 5, 1, "rccl-self")):
+    for N, P, K, steps, transport in ((64, 1, 7, 2, "copy"), (64, 4, 6, 1, "copy"), (96, 2, 11, 1, "rccl-self"),
+                                      (96, 3, 20, 1, "copy")):
         got, want = run_case(N, P, K, steps, transport)
         for n in got:
             assert_same(got[n], want[n], f"{env} N={N} P={P} K={K} {transport}: {n}")
