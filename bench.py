@@ -292,7 +292,7 @@ def main():
     fs.close()
 
     # ---- N > 1: the same grid on ONE GPU (rank 0's), in the same run: the denominator of `speedup` ----
-    if world > 1 and args.single_steps > 0 and not loopback:
+    if world > 1 and args.single_steps > 0:
         if dist is not None:
             dist.barrier()  # every rank has released its slab
         if rank == 0:

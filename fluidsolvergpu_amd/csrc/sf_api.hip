@@ -1652,8 +1652,8 @@ private:
             const bool pair = can_fuse2() && it + 2 <= K;
             // three sweeps per pass where the S-sweep kernel is in use (never the first pass of a solve, whose iterate
             // is caller data; a remainder of four goes as 2 + 2)
-            const int step = sweeps_in_launch(it, K, continued, 0);
             x_is_zero_ = x_zero && it == 0 && pair;  // the first fused pair then loads no x at all
+            const int step = sweeps_in_launch(it, K, continued, 0);
             const int depth0 = std::max(step == 2 ? pair_depth() : step, G_);  // boundary depth without growth
             int extra = 0;
             {
