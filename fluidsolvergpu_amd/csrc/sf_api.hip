@@ -281,7 +281,7 @@ public:
         march_min_planes_ = env_int("SF_MARCH_MINP", 12);
         march_min_cells_ = (long)env_int("SF_MARCH_MINCELLS_K", 6000) * 1000L;  // ~182^3
         sk2_min_cells_ = std::max(march_min_cells_ == 0 ? 0L : 60000000L, march_min_cells_);  // ~390^3
-        sk_s_ = env_int("SF_SK_S", 3);
+        sk_s_ = env_int("SF_SK_S", 4);
         sk_cfg_ = env_int("SF_SK_CFG", -1);  // tile shape: -1 automatic, 0..3 see SF_SK_CFGS
         sk_kc_ = env_int("SF_SK_KC", 0);
         sk_wgcu_ = env_int("SF_SK_WGCU", 0);
@@ -1547,18 +1547,24 @@ private:
                 }
             } else {
                 if constexpr ((SF_SK_CFGS & 1) != 0) {
+                    // four levels hold 21 planes of rows per lane: four rows per wave fit 256 registers in fp32 (five
+                    // spill: 256^3 27.6 vs 17.7 us/sweep), five in fp64 (one 8-byte cell per lane, no packed pairs)
+                    constexpr int TJ0 = S == 4 ? (sizeof(T) == 4 ? 4 : 5) : 6;
                     if (nt)
-                        launch_sk_cfg<true, S, 6, 8>(sl, B, kb, ke, last);
+                        launch_sk_cfg<true, S, TJ0, 8>(sl, B, kb, ke, last);
                     else
-                        launch_sk_cfg<false, S, 6, 8>(sl, B, kb, ke, last);
+                        launch_sk_cfg<false, S, TJ0, 8>(sl, B, kb, ke, last);
                 }
             }
         }
     }
 
     template <int NF>
-    void launch_jacobi3(Slab& sl, const sfk::JacobiArgs<T, NF>& A, int kb, int ke, bool last) {
-        launch_sk<NF, 3>(sl, A, kb, ke, last);
+    void launch_jacobi_s(Slab& sl, const sfk::JacobiArgs<T, NF>& A, int kb, int ke, bool last, int sweeps) {
+        if (sweeps == 4)
+            launch_sk<NF, 4>(sl, A, kb, ke, last);
+        else
+            launch_sk<NF, 3>(sl, A, kb, ke, last);
     }
 
     template <int NF, bool SRC = false>
@@ -1605,6 +1611,9 @@ private:
             triple = G_ == 3 && split_enabled_ && interior >= march_min_planes_ &&
                      (long)N_ * N_ * interior >= march_min_cells_;
         }
+        // four sweeps per pass on an undecomposed grid (a slab boundary would need four ghost planes); remainders of
+        // 5 and 6 go as 3 + 2 and 3 + 3
+        if (triple && P_ == 1 && sk_s_ >= 4 && left >= 4 && left != 5 && left != 6) return 4;
         return triple ? 3 : (pair ? 2 : 1);
     }
     // boundary depth of a two-sweep launch: the register-blocked pair kernel works on plane pairs, and a plane block
@@ -1667,7 +1676,7 @@ private:
                 extra = cont ? d - depth0 : 0;
                 dprev = depth0 + extra;
             }
-            const bool triple = step == 3;
+            const bool triple = step >= 3;  // three or four sweeps: the marching kernel
             trap_extra_ = extra;
             ++tj;
             for_planes([&](Slab& sl, int kb, int ke) {
@@ -1681,7 +1690,7 @@ private:
                 A.a = a;
                 A.inv = inv;
                 if (triple)
-                    launch_jacobi3<NF>(sl, A, kb, ke, it + step == K);
+                    launch_jacobi_s<NF>(sl, A, kb, ke, it + step == K, step);
                 else if (pair)
                     launch_jacobi2<NF>(sl, A, kb, ke, it == 0 && !continued, it + step == K);
                 else
@@ -1875,7 +1884,7 @@ private:
     int fuse2_ = 1, kc2_ = 32;
     int march_k_ = 1, march_min_planes_ = 12;
     long march_min_cells_ = 6000000, sk2_min_cells_ = 60000000;
-    int sk_s_ = 3, sk_cfg_ = -1, sk_kc_ = 0, sk_wgcu_ = 0;
+    int sk_s_ = 4, sk_cfg_ = -1, sk_kc_ = 0, sk_wgcu_ = 0;
     long plane_ = 0, field_elems_ = 0;
     std::vector<Slab> slabs_;
     ncclComm_t comm_ = nullptr;

@@ -1094,8 +1094,9 @@ template <class T, int WL, bool NT, int S, int TJ, int NW, int PH, int NACT, boo
 __device__ __forceinline__ void jsk_step(const Geom& g, SkShared<T, WL, S, TJ, NW>& sh,
                                          typename LaneVec<T, WL>::type (&xr)[4][TJ],
                                          typename LaneVec<T, WL>::type (&yr)[S - 1][4][TJ],
-                                         typename LaneVec<T, WL>::type (&sr)[4][TJ], const unsigned (&rowb)[TJ],
-                                         const unsigned (&rowst)[TJ], const T* __restrict__& px,
+                                         typename LaneVec<T, WL>::type (&sr)[S == 4 ? 5 : 4][TJ],
+                                         const unsigned (&rowb)[TJ], const unsigned (&rowst)[TJ],
+                                         const T* __restrict__& px,
                                          const T* __restrict__& ps0, T* __restrict__& pout, int kk, T a, T inv, T sx,
                                          T sy, T sz, int jrow0, int wave, int lane, bool first_vec, bool last_vec) {
     typedef typename LaneVec<T, WL>::type VW;
@@ -1107,12 +1108,25 @@ __device__ __forceinline__ void jsk_step(const Geom& g, SkShared<T, WL, S, TJ, N
     {
         const __amdgpu_buffer_rsrc_t rd = plane_rsrc(px);
         const __amdgpu_buffer_rsrc_t rs = plane_rsrc(ps0);
-        px += (kk + 2 < kmax) ? g.plane : 0;
-        ps0 += (kk + 1 < kmax) ? g.plane : 0;
+        // (held at plane 0 while the index is still negative — a chunk that starts at the first plane reaches S-1
+        // planes below it — and at the last stored plane beyond it: values requested outside are never used)
+        px += (kk + 2 >= 0 && kk + 2 < kmax) ? g.plane : 0;
+        ps0 += (kk + 1 >= 0 && kk + 1 < kmax) ? g.plane : 0;
 #pragma unroll
         for (int r = 0; r < TJ; ++r) xr[(PH + 2) & 3][r] = buf_load<T, WL>(rd, rowb[r]);
+        if constexpr (S == 4) {
+            // five planes of x0 are live with four levels (one in flight): not a divisor of the four-fold unrolled
+            // march, so x0 is a shift register: slot l serves level l, slot 0 receives the request
 #pragma unroll
-        for (int r = 0; r < TJ; ++r) sr[(PH + 1) & 3][r] = buf_load<T, WL>(rs, rowb[r]);
+            for (int l = 4; l >= 1; --l)
+#pragma unroll
+                for (int r = 0; r < TJ; ++r) sr[l][r] = sr[l - 1][r];
+#pragma unroll
+            for (int r = 0; r < TJ; ++r) sr[0][r] = buf_load<T, WL>(rs, rowb[r]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < TJ; ++r) sr[(PH + 1) & 3][r] = buf_load<T, WL>(rs, rowb[r]);
+        }
     }
     // (2) the neighbours' edge rows of every active source level (published in the previous step)
     const int wlo = wave > 0 ? wave - 1 : 0, whi = wave < NW - 1 ? wave + 1 : NW - 1;
@@ -1183,7 +1197,7 @@ __device__ __forceinline__ void jsk_step(const Geom& g, SkShared<T, WL, S, TJ, N
                 if (klo) km = sz * cc;
                 if (khi) kp = sz * cc;
             }
-            const VW s = sr[(PH + 5 - l) & 3][r];
+            const VW s = (S == 4) ? sr[l < 5 ? l : 0][r] : sr[(PH + 5 - l) & 3][r];
             VW o;
 #pragma unroll
             for (int e = 0; e < WL; ++e) o[e] = (s[e] + a * ((lr[e] + (jm[e] + jp[e])) + (km[e] + kp[e]))) * inv;
@@ -1265,13 +1279,13 @@ __device__ __forceinline__ void jsk_march(const Geom& g, SkShared<T, WL, S, TJ, 
                                           const T* __restrict__ x0, T* __restrict__ xn, int k0, int k1, T a, T inv, T sx,
                                           T sy, T sz, int jrow0, int wave, int lane, bool first_vec, bool last_vec) {
     typedef typename LaneVec<T, WL>::type VW;
-    static_assert(S == 2 || S == 3, "two or three fused sweeps");
+    static_assert(S >= 2 && S <= 4, "two, three or four fused sweeps");
     const int kmax = g.np - 1;
     auto plane_of_k = [&](const T* base, int kl) -> __amdgpu_buffer_rsrc_t {
         kl = kl < 0 ? 0 : (kl > kmax ? kmax : kl);
         return plane_rsrc(base + (long)kl * g.plane);
     };
-    VW xr[4][TJ], yr[S - 1][4][TJ], sr[4][TJ];
+    VW xr[4][TJ], yr[S - 1][4][TJ], sr[S == 4 ? 5 : 4][TJ];
     int kk = k0 - S + 1;  // first step; ring phase 0
     {
         // planes kk-1, kk, kk+1 of x in ring slots 3, 0, 1; x0(kk) in slot 0
@@ -1289,9 +1303,9 @@ __device__ __forceinline__ void jsk_march(const Geom& g, SkShared<T, WL, S, TJ, 
         sh.edge[1][0][wave][1][lane] = xr[0][TJ - 1];
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
-    // running plane pointers: x(kk+2), x0(kk+1) (k0 >= 1, so both indices are >= 0) and the output plane k0
-    const T* __restrict__ px = x + (long)(kk + 2 > kmax ? kmax : kk + 2) * g.plane;
-    const T* __restrict__ ps0 = x0 + (long)(kk + 1 > kmax ? kmax : kk + 1) * g.plane;
+    // running plane pointers: x(kk+2), x0(kk+1), clamped into the stored planes [0, kmax], and the output plane k0
+    const T* __restrict__ px = x + (long)(kk + 2 > kmax ? kmax : (kk + 2 < 0 ? 0 : kk + 2)) * g.plane;
+    const T* __restrict__ ps0 = x0 + (long)(kk + 1 > kmax ? kmax : (kk + 1 < 0 ? 0 : kk + 1)) * g.plane;
     T* __restrict__ pout = xn + (long)k0 * g.plane;
 #define SF_SK_STEP(PH_, NACT_)                                                                                       \
     jsk_step<T, WL, NT, S, TJ, NW, PH_, NACT_, WALLS, ISH, ROWEND>(g, sh, xr, yr, sr, rowb, rowst, px, ps0, pout, kk, a, \
@@ -1313,7 +1327,7 @@ __device__ __forceinline__ void jsk_march(const Geom& g, SkShared<T, WL, S, TJ, 
             SF_SK_STEP(1, 2);
             if (++kk > kend) break;
         }
-    } else {
+    } else if constexpr (S == 3) {
         SF_SK_STEP(2, 2);
         ++kk;
         SF_SK_STEP(3, 2);
@@ -1326,6 +1340,25 @@ __device__ __forceinline__ void jsk_march(const Geom& g, SkShared<T, WL, S, TJ, 
             SF_SK_STEP(2, 3);
             if (++kk > kend) break;
             SF_SK_STEP(3, 3);
+            if (++kk > kend) break;
+        }
+    } else {
+        SF_SK_STEP(2, 2);
+        ++kk;
+        SF_SK_STEP(3, 2);
+        ++kk;
+        SF_SK_STEP(0, 3);
+        ++kk;
+        SF_SK_STEP(1, 3);
+        ++kk;
+        for (;;) {
+            SF_SK_STEP(2, 4);
+            if (++kk > kend) break;
+            SF_SK_STEP(3, 4);
+            if (++kk > kend) break;
+            SF_SK_STEP(0, 4);
+            if (++kk > kend) break;
+            SF_SK_STEP(1, 4);
             if (++kk > kend) break;
         }
     }
