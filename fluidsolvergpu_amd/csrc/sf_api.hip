@@ -285,6 +285,7 @@ public:
         sk_cfg_ = env_int("SF_SK_CFG", -1);  // tile shape: -1 automatic, 0..3 see SF_SK_CFGS
         sk_kc_ = env_int("SF_SK_KC", 0);
         sk_wgcu_ = env_int("SF_SK_WGCU", 0);
+        sk_first_ = env_int("SF_SK_FIRST", 1) != 0;  // first pass of a solve through the marching kernel
         SF_HIP(hipDeviceSynchronize());
         if ((nranks_ > 1 || rccl_self_) && std::getenv("SF_TRAP") == nullptr && env_int("SF_AUTOTUNE", 1)) tune_schedule();
     }
@@ -1473,7 +1474,7 @@ private:
         }
         return nchunk;
     }
-    template <bool NT, int S, int TJ, int NW>
+    template <bool NT, int S, int TJ, int NW, int FIRST = 0>
     void launch_sk_cfg(Slab& sl, const sfk::JacobiArgs<T, 1>& A, int kb, int ke, bool last) {
         constexpr int WL = W / 2;  // 8 bytes per lane
         constexpr int V = NW * TJ - 2 * S, P = 64 - 2 * ((S + WL - 1) / WL);
@@ -1500,10 +1501,50 @@ private:
         m.kc = split_ != INT_MAX ? split_ : ceil_div(np, nchunk);
         nchunk = ceil_div(np, m.kc);
         const dim3 nb(8u, (unsigned)m.band, (unsigned)nchunk);
-        if (last)
-            launch_k(sl, sfk::jacobi_sk_kernel<T, 1, WL, NT, S, TJ, NW, true>, nb, 64u * NW, sl.geom, A, kb, ke, m);
-        else
-            launch_k(sl, sfk::jacobi_sk_kernel<T, 1, WL, NT, S, TJ, NW, false>, nb, 64u * NW, sl.geom, A, kb, ke, m);
+        if constexpr (FIRST != 0) {  // a first pass is never the last one (sk_first_ok)
+            launch_k(sl, sfk::jacobi_sk_kernel<T, 1, WL, NT, S, TJ, NW, false, FIRST>, nb, 64u * NW, sl.geom, A, kb, ke, m);
+        } else {
+            if (last)
+                launch_k(sl, sfk::jacobi_sk_kernel<T, 1, WL, NT, S, TJ, NW, true>, nb, 64u * NW, sl.geom, A, kb, ke, m);
+            else
+                launch_k(sl, sfk::jacobi_sk_kernel<T, 1, WL, NT, S, TJ, NW, false>, nb, 64u * NW, sl.geom, A, kb, ke, m);
+        }
+    }
+
+    // First pass of a solve through the marching kernel (four sweeps; sfk::SkFirst): mode 1 caller data, 2 folded
+    // add_source, 3 zero iterate. One launch per field.
+    template <int NF>
+    void launch_sk_first(Slab& sl, const sfk::JacobiArgs<T, NF>& A, int kb, int ke, int mode) {
+        const bool nt = nt_mode_ == 1 ||
+                        (nt_mode_ == 2 && (size_t)field_elems_ * sizeof(T) * 3 * NF > ((size_t)384 << 20));
+        constexpr int TJ0 = sizeof(T) == 4 ? 4 : 5;
+        for (int f = 0; f < NF; ++f) {
+            sfk::JacobiArgs<T, 1> B;
+            B.x[0] = A.x[f];
+            B.x0[0] = A.x0[f];
+            B.xn[0] = A.xn[f];
+            B.x0out[0] = A.x0out[f];
+            B.b[0] = A.b[f];
+            B.a = A.a;
+            B.inv = A.inv;
+            B.dt = A.dt;
+            if (mode == 1) {
+                if (nt) launch_sk_cfg<true, 4, TJ0, 8, 1>(sl, B, kb, ke, false);
+                else launch_sk_cfg<false, 4, TJ0, 8, 1>(sl, B, kb, ke, false);
+            } else if (mode == 2) {
+                if (nt) launch_sk_cfg<true, 4, TJ0, 8, 2>(sl, B, kb, ke, false);
+                else launch_sk_cfg<false, 4, TJ0, 8, 2>(sl, B, kb, ke, false);
+            } else {
+                if (nt) launch_sk_cfg<true, 4, TJ0, 8, 3>(sl, B, kb, ke, false);
+                else launch_sk_cfg<false, 4, TJ0, 8, 3>(sl, B, kb, ke, false);
+            }
+        }
+    }
+    // May the FIRST pass of a K-sweep solve go through the marching kernel? Undecomposed grid, four-sweep launches
+    // enabled, a grid the kernel takes, and sweeps left over afterwards (no i-shell-writing variant of a first pass).
+    bool sk_first_ok(int K) const {
+        return sk_first_ && march_k_ != 0 && sk_s_ >= 4 && P_ == 1 && can_fuse2() && ishell_skip_ && K >= 7 &&
+               nzl_ >= march_min_planes_ && (long)N_ * N_ * nzl_ >= march_min_cells_;
     }
 
     template <int NF, int S>
@@ -1602,19 +1643,21 @@ private:
     int sweeps_in_launch(int it, int K, bool continued, int extra = 0) const {
         const bool pair = can_fuse2() && it + 2 <= K;
         const int left = K - it;
-        bool triple = pair && (it > 0 || continued) && march_k_ != 0 && sk_s_ >= 3 && left >= 3 && left != 4;
-        if (triple && P_ == 1) triple = can_sk(nzl_, false);
-        if (triple && P_ > 1) {
+        if (it == 0 && !continued && sk_first_ok(K)) return 4;
+        bool marching = pair && (it > 0 || continued) && march_k_ != 0 && sk_s_ >= 3 && left >= 3;
+        if (marching && P_ == 1) marching = can_sk(nzl_, false);
+        if (marching && P_ > 1) {
             // decomposed: three ghost planes, the two-stream schedule, and an interior launch [G+3+extra, ...) the
             // marching kernel takes (the boundary launch always goes through it: there is no other three-sweep kernel)
             const int interior = nzl_ - 2 * (3 + extra);
-            triple = G_ == 3 && split_enabled_ && interior >= march_min_planes_ &&
-                     (long)N_ * N_ * interior >= march_min_cells_;
+            marching = G_ == 3 && split_enabled_ && interior >= march_min_planes_ &&
+                       (long)N_ * N_ * interior >= march_min_cells_;
         }
         // four sweeps per pass on an undecomposed grid (a slab boundary would need four ghost planes); remainders of
-        // 5 and 6 go as 3 + 2 and 3 + 3
-        if (triple && P_ == 1 && sk_s_ >= 4 && left >= 4 && left != 5 && left != 6) return 4;
-        return triple ? 3 : (pair ? 2 : 1);
+        // 5 and 6 go as 3 + 2 and 3 + 3; without four-sweep launches a remainder of 4 goes as 2 + 2
+        if (marching && P_ == 1 && sk_s_ >= 4 && left >= 4 && left != 5 && left != 6) return 4;
+        if (marching && left != 4) return 3;
+        return pair ? 2 : 1;
     }
     // boundary depth of a two-sweep launch: the register-blocked pair kernel works on plane pairs, and a plane block
     // must not straddle the split of a boundary launch, so with three ghost planes it takes four planes per side
@@ -1689,7 +1732,9 @@ private:
                 }
                 A.a = a;
                 A.inv = inv;
-                if (triple)
+                if (it == 0 && !continued && step == 4)
+                    launch_sk_first<NF>(sl, A, kb, ke, x_zero ? 3 : 1);
+                else if (triple)
                     launch_jacobi_s<NF>(sl, A, kb, ke, it + step == K, step);
                 else if (pair)
                     launch_jacobi2<NF>(sl, A, kb, ke, it == 0 && !continued, it + step == K);
@@ -1739,6 +1784,28 @@ private:
                 ensure(sl, x0[f]);
                 ensure(sl, src[f]);
             }
+        if (sk_first_ok(K)) {
+            // the same pass as four sweeps of the marching kernel (undecomposed grid): rhs formed per plane as it
+            // arrives, stored for the later launches
+            for_planes([&](Slab& sl, int kb, int ke) {
+                sfk::JacobiArgs<T, NF> A;
+                for (int f = 0; f < NF; ++f) {
+                    A.x[f] = sl.field[src[f]];
+                    A.x0[f] = sl.field[x[f]];
+                    A.xn[f] = sl.scratch[f];
+                    A.x0out[f] = sl.field[x0[f]];
+                    A.b[f] = b[f];
+                }
+                A.a = a;
+                A.inv = inv;
+                A.dt = dt_;
+                launch_sk_first<NF>(sl, A, kb, ke, 2);
+            }, 4, true);
+            for (Slab& sl : slabs_)
+                for (int f = 0; f < NF; ++f) std::swap(sl.field[x[f]], sl.scratch[f]);
+            op_lin_solve<NF>(x, x0, b, a, c, K - 4, false, true);
+            return;
+        }
         for_planes([&](Slab& sl, int kb, int ke) {
             sfk::JacobiArgs<T, NF> A;
             for (int f = 0; f < NF; ++f) {
@@ -1885,6 +1952,7 @@ private:
     int march_k_ = 1, march_min_planes_ = 12;
     long march_min_cells_ = 6000000, sk2_min_cells_ = 60000000;
     int sk_s_ = 4, sk_cfg_ = -1, sk_kc_ = 0, sk_wgcu_ = 0;
+    bool sk_first_ = true;
     long plane_ = 0, field_elems_ = 0;
     std::vector<Slab> slabs_;
     ncclComm_t comm_ = nullptr;

@@ -983,6 +983,16 @@ __device__ __forceinline__ void buf_store1(__amdgpu_buffer_rsrc_t r, unsigned of
     }
 }
 
+template <class T>
+__device__ __forceinline__ T buf_load1(__amdgpu_buffer_rsrc_t r, unsigned off) {  // out of range: returns 0
+    if constexpr (sizeof(T) == 4) {
+        return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+    } else {
+        typedef int I2 __attribute__((ext_vector_type(2)));
+        return __builtin_bit_cast(T, (I2)__builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0));
+    }
+}
+
 // set_bnd fused into the marching kernel: emit_shells with every address formed from a plane resource (wave-uniform)
 // and the byte offsets of rows j-1, j, j+1 the lane already holds — no address registers of its own. Same
 // expressions, same bits. `o` holds the WL interior cells at row j of plane ko; rm / rc / rp: planes ko-1, ko, ko+1.
@@ -1090,7 +1100,23 @@ struct SkShared {
     typename LaneVec<T, WL>::type edge[2][S][NW][2][64];  // [buffer][level 0..S-1][wave][first/last row][lane]
 };
 
-template <class T, int WL, bool NT, int S, int TJ, int NW, int PH, int NACT, bool WALLS, bool ISH, bool ROWEND>
+// The FIRST pass of a solve inside the marching kernel (FIRST != 0; four-sweep launches only). Its iterate is not the
+// output of an earlier sweep, so level 1 differs:
+//   1  caller data: the i = 0 / N+1 shell cells of x are READ (one unconditional dword load per row whose offset is
+//      out of range for every lane that is not at a row end), not recomputed;
+//   2  diffuse with add_source folded in: x is the source array (Stam's initial guess, i-shell read as in 1), x0 the
+//      field before add_source; rhs = x0 + dt * x (the expression of add_source_kernel) replaces x0 for every level
+//      the moment its plane arrives and is stored to x0out for the later launches (interior cells of the chunk);
+//   3  project: the iterate is identically zero — no x is requested at all, level 1 is evaluated on literal zeros.
+template <class T, int TJ>
+struct SkFirst {
+    T xs[4][TJ];         // ring of the row-end shell cells of x (modes 1, 2)
+    T* __restrict__ prhs;  // mode 2: plane kk of x0out (clamped like px)
+    T dt;
+    int k0, k1;
+};
+
+template <class T, int WL, bool NT, int S, int TJ, int NW, int PH, int NACT, bool WALLS, bool ISH, bool ROWEND, int FIRST>
 __device__ __forceinline__ void jsk_step(const Geom& g, SkShared<T, WL, S, TJ, NW>& sh,
                                          typename LaneVec<T, WL>::type (&xr)[4][TJ],
                                          typename LaneVec<T, WL>::type (&yr)[S - 1][4][TJ],
@@ -1098,10 +1124,13 @@ __device__ __forceinline__ void jsk_step(const Geom& g, SkShared<T, WL, S, TJ, N
                                          const unsigned (&rowb)[TJ], const unsigned (&rowst)[TJ],
                                          const T* __restrict__& px,
                                          const T* __restrict__& ps0, T* __restrict__& pout, int kk, T a, T inv, T sx,
-                                         T sy, T sz, int jrow0, int wave, int lane, bool first_vec, bool last_vec) {
+                                         T sy, T sz, int jrow0, int wave, int lane, bool first_vec, bool last_vec,
+                                         SkFirst<T, TJ>& fx) {
     typedef typename LaneVec<T, WL>::type VW;
+    static_assert(FIRST == 0 || S == 4, "first passes exist as four-sweep launches only");
     const int N = g.N;
     const int kmax = g.np - 1;
+    constexpr unsigned OOBL = 0xFFFFFF00u;
     constexpr int RB = (PH + 1) & 1, WB = PH & 1;  // LDS buffer read (written one step ago) / written in this step
     // (1) requests for the next step: x(kk+2), x0(kk+1). px / ps0 point at those planes and advance by one plane per
     // step (held at the last stored plane: the values requested beyond it are never used)
@@ -1112,8 +1141,18 @@ __device__ __forceinline__ void jsk_step(const Geom& g, SkShared<T, WL, S, TJ, N
         // planes below it — and at the last stored plane beyond it: values requested outside are never used)
         px += (kk + 2 >= 0 && kk + 2 < kmax) ? g.plane : 0;
         ps0 += (kk + 1 >= 0 && kk + 1 < kmax) ? g.plane : 0;
+        if constexpr (FIRST != 3) {
 #pragma unroll
-        for (int r = 0; r < TJ; ++r) xr[(PH + 2) & 3][r] = buf_load<T, WL>(rd, rowb[r]);
+            for (int r = 0; r < TJ; ++r) xr[(PH + 2) & 3][r] = buf_load<T, WL>(rd, rowb[r]);
+        }
+        if constexpr ((FIRST == 1 || FIRST == 2) && ROWEND) {
+#pragma unroll
+            for (int r = 0; r < TJ; ++r) {
+                const unsigned off = first_vec ? rowb[r] - (unsigned)sizeof(T)
+                                               : (last_vec ? rowb[r] + WL * (unsigned)sizeof(T) : OOBL);
+                fx.xs[(PH + 2) & 3][r] = buf_load1<T>(rd, off);
+            }
+        }
         if constexpr (S == 4) {
             // five planes of x0 are live with four levels (one in flight): not a divisor of the four-fold unrolled
             // march, so x0 is a shift register: slot l serves level l, slot 0 receives the request
@@ -1128,11 +1167,34 @@ __device__ __forceinline__ void jsk_step(const Geom& g, SkShared<T, WL, S, TJ, N
             for (int r = 0; r < TJ; ++r) sr[(PH + 1) & 3][r] = buf_load<T, WL>(rs, rowb[r]);
         }
     }
+    if constexpr (FIRST == 2) {
+        // x0(kk) has arrived (slot 1 after the shift) and x(kk) = the source is the centre plane of level 1: form the
+        // right-hand side of this plane once, for every level, and store it where the later launches read it
+        const bool inr = kk >= fx.k0 && kk < fx.k1;  // wave-uniform: planes of this chunk
+        const __amdgpu_buffer_rsrc_t rr = plane_rsrc(fx.prhs);
+        fx.prhs += (kk >= 0 && kk < kmax) ? g.plane : 0;
+#pragma unroll
+        for (int r = 0; r < TJ; ++r) {
+            VW rhs;
+#pragma unroll
+            for (int e = 0; e < WL; ++e) rhs[e] = sr[1][r][e] + fx.dt * xr[(PH + 0) & 3][r][e];
+            sr[1][r] = rhs;
+            buf_store<T, WL, false>(rr, inr ? rowst[r] : OOBL, rhs);
+        }
+    }
     // (2) the neighbours' edge rows of every active source level (published in the previous step)
     const int wlo = wave > 0 ? wave - 1 : 0, whi = wave < NW - 1 ? wave + 1 : NW - 1;
     VW hm[S], hp[S];
 #pragma unroll
     for (int l = 1; l <= NACT; ++l) {
+        if (FIRST == 3 && l == 1) {
+#pragma unroll
+            for (int e = 0; e < WL; ++e) {
+                hm[0][e] = T(0);
+                hp[0][e] = T(0);
+            }
+            continue;
+        }
         hm[l - 1] = sh.edge[RB][l - 1][wlo][1][lane];
         hp[l - 1] = sh.edge[RB][l - 1][whi][0][lane];
     }
@@ -1150,7 +1212,10 @@ __device__ __forceinline__ void jsk_step(const Geom& g, SkShared<T, WL, S, TJ, N
 #pragma unroll
         for (int r = 0; r < TJ; ++r) {
             VW cc, km, kp, jm, jp;
-            if (l == 1) {
+            if (l == 1 && FIRST == 3) {
+#pragma unroll
+                for (int e = 0; e < WL; ++e) cc[e] = km[e] = kp[e] = jm[e] = jp[e] = T(0);
+            } else if (l == 1) {
                 cc = xr[(PH + 0) & 3][r];
                 km = xr[(PH + 3) & 3][r];
                 kp = xr[(PH + 1) & 3][r];
@@ -1168,20 +1233,27 @@ __device__ __forceinline__ void jsk_step(const Geom& g, SkShared<T, WL, S, TJ, N
             // (left + right): the i-neighbours of the lane's end cells live in the adjacent lanes; at a row end they
             // are the i-shell cells sx * (end cell) instead (ROWEND: does this workgroup hold a row end at all?)
             VW lr;
-            if constexpr (WL == 2 && sizeof(T) == 4) {
+            // the i-shell cell at a row end: sx * (end cell) — the set_bnd of the previous sweep, recomputed — or, in
+            // level 1 of a first pass over caller data, the cell as it stands in memory
+            const bool shell_mem = (FIRST == 1 || FIRST == 2) && l == 1;
+            const T xsv = shell_mem ? fx.xs[(PH + 0) & 3][r] : T(0);
+            if (FIRST == 3 && l == 1) {
+#pragma unroll
+                for (int e = 0; e < WL; ++e) lr[e] = T(0) + T(0);
+            } else if constexpr (WL == 2 && sizeof(T) == 4) {
                 T e0, e1;
                 lr_sum2(cc[0], cc[1], e0, e1);
                 if constexpr (ROWEND) {
-                    e0 = first_vec ? sx * cc[0] + cc[1] : e0;
-                    e1 = last_vec ? cc[0] + sx * cc[1] : e1;
+                    e0 = first_vec ? (shell_mem ? xsv : sx * cc[0]) + cc[1] : e0;
+                    e1 = last_vec ? cc[0] + (shell_mem ? xsv : sx * cc[1]) : e1;
                 }
                 lr[0] = e0;
                 lr[1] = e1;
             } else {
                 const T up = lane_up(cc[WL - 1]);
                 const T dn = lane_dn(cc[0]);
-                const T cm = (ROWEND && first_vec) ? sx * cc[0] : up;
-                const T cp = (ROWEND && last_vec) ? sx * cc[WL - 1] : dn;
+                const T cm = (ROWEND && first_vec) ? (shell_mem ? xsv : sx * cc[0]) : up;
+                const T cp = (ROWEND && last_vec) ? (shell_mem ? xsv : sx * cc[WL - 1]) : dn;
 #pragma unroll
                 for (int e = 0; e < WL; ++e) {
                     const T left = (e == 0) ? cm : cc[e > 0 ? e - 1 : 0];
@@ -1260,8 +1332,10 @@ __device__ __forceinline__ void jsk_step(const Geom& g, SkShared<T, WL, S, TJ, N
         }
     }
     // (4) publish this wave's edge rows: x(kk+1) and every intermediate level computed in this step
-    sh.edge[WB][0][wave][0][lane] = xr[(PH + 1) & 3][0];
-    sh.edge[WB][0][wave][1][lane] = xr[(PH + 1) & 3][TJ - 1];
+    if constexpr (FIRST != 3) {
+        sh.edge[WB][0][wave][0][lane] = xr[(PH + 1) & 3][0];
+        sh.edge[WB][0][wave][1][lane] = xr[(PH + 1) & 3][TJ - 1];
+    }
 #pragma unroll
     for (int l = 1; l < S; ++l)
         if (l <= NACT) {
@@ -1273,11 +1347,12 @@ __device__ __forceinline__ void jsk_step(const Geom& g, SkShared<T, WL, S, TJ, N
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <class T, int WL, bool NT, int S, int TJ, int NW, bool WALLS, bool ISH, bool ROWEND>
+template <class T, int WL, bool NT, int S, int TJ, int NW, bool WALLS, bool ISH, bool ROWEND, int FIRST>
 __device__ __forceinline__ void jsk_march(const Geom& g, SkShared<T, WL, S, TJ, NW>& sh, const unsigned (&rowb)[TJ],
                                           const unsigned (&rowst)[TJ], const T* __restrict__ x,
                                           const T* __restrict__ x0, T* __restrict__ xn, int k0, int k1, T a, T inv, T sx,
-                                          T sy, T sz, int jrow0, int wave, int lane, bool first_vec, bool last_vec) {
+                                          T sy, T sz, int jrow0, int wave, int lane, bool first_vec, bool last_vec,
+                                          T* __restrict__ x0out, T dt) {
     typedef typename LaneVec<T, WL>::type VW;
     static_assert(S >= 2 && S <= 4, "two, three or four fused sweeps");
     const int kmax = g.np - 1;
@@ -1287,20 +1362,43 @@ __device__ __forceinline__ void jsk_march(const Geom& g, SkShared<T, WL, S, TJ, 
     };
     VW xr[4][TJ], yr[S - 1][4][TJ], sr[S == 4 ? 5 : 4][TJ];
     int kk = k0 - S + 1;  // first step; ring phase 0
+    SkFirst<T, TJ> fx;
+    fx.dt = dt;
+    fx.k0 = k0;
+    fx.k1 = k1;
+    fx.prhs = x0out + (long)(kk > kmax ? kmax : (kk < 0 ? 0 : kk)) * g.plane;
     {
         // planes kk-1, kk, kk+1 of x in ring slots 3, 0, 1; x0(kk) in slot 0
         const __amdgpu_buffer_rsrc_t pa = plane_of_k(x, kk - 1), pb = plane_of_k(x, kk), pc = plane_of_k(x, kk + 1);
         const __amdgpu_buffer_rsrc_t ps = plane_of_k(x0, kk);
 #pragma unroll
         for (int r = 0; r < TJ; ++r) {
-            xr[3][r] = buf_load<T, WL>(pa, rowb[r]);
-            xr[0][r] = buf_load<T, WL>(pb, rowb[r]);
-            xr[1][r] = buf_load<T, WL>(pc, rowb[r]);
+            if constexpr (FIRST != 3) {
+                xr[3][r] = buf_load<T, WL>(pa, rowb[r]);
+                xr[0][r] = buf_load<T, WL>(pb, rowb[r]);
+                xr[1][r] = buf_load<T, WL>(pc, rowb[r]);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int e = 0; e < WL; ++e) xr[q][r][e] = T(0);
+            }
             sr[0][r] = buf_load<T, WL>(ps, rowb[r]);
         }
+        if constexpr ((FIRST == 1 || FIRST == 2) && ROWEND) {
+#pragma unroll
+            for (int r = 0; r < TJ; ++r) {
+                const unsigned off = first_vec ? rowb[r] - (unsigned)sizeof(T)
+                                               : (last_vec ? rowb[r] + WL * (unsigned)sizeof(T) : 0xFFFFFF00u);
+                fx.xs[0][r] = buf_load1<T>(pb, off);
+                fx.xs[1][r] = buf_load1<T>(pc, off);
+            }
+        }
         // the first step reads the edges of x(kk) from buffer 1
-        sh.edge[1][0][wave][0][lane] = xr[0][0];
-        sh.edge[1][0][wave][1][lane] = xr[0][TJ - 1];
+        if constexpr (FIRST != 3) {
+            sh.edge[1][0][wave][0][lane] = xr[0][0];
+            sh.edge[1][0][wave][1][lane] = xr[0][TJ - 1];
+        }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
     // running plane pointers: x(kk+2), x0(kk+1), clamped into the stored planes [0, kmax], and the output plane k0
@@ -1308,9 +1406,9 @@ __device__ __forceinline__ void jsk_march(const Geom& g, SkShared<T, WL, S, TJ, 
     const T* __restrict__ ps0 = x0 + (long)(kk + 1 > kmax ? kmax : (kk + 1 < 0 ? 0 : kk + 1)) * g.plane;
     T* __restrict__ pout = xn + (long)k0 * g.plane;
 #define SF_SK_STEP(PH_, NACT_)                                                                                       \
-    jsk_step<T, WL, NT, S, TJ, NW, PH_, NACT_, WALLS, ISH, ROWEND>(g, sh, xr, yr, sr, rowb, rowst, px, ps0, pout, kk, a, \
-                                                                   inv, sx, sy, sz, jrow0, wave, lane, first_vec,      \
-                                                                   last_vec)
+    jsk_step<T, WL, NT, S, TJ, NW, PH_, NACT_, WALLS, ISH, ROWEND, FIRST>(g, sh, xr, yr, sr, rowb, rowst, px, ps0, pout, \
+                                                                          kk, a, inv, sx, sy, sz, jrow0, wave, lane,    \
+                                                                          first_vec, last_vec, fx)
     const int kend = k1 + S - 2;  // last step
     SF_SK_STEP(0, 1);
     ++kk;
@@ -1369,7 +1467,7 @@ __device__ __forceinline__ void jsk_march(const Geom& g, SkShared<T, WL, S, TJ, 
 #define SF_SK_WAVES 2
 #endif
 
-template <class T, int NF, int WL, bool NT, int S, int TJ, int NW, bool ISH>
+template <class T, int NF, int WL, bool NT, int S, int TJ, int NW, bool ISH, int FIRST = 0>
 __global__ void __launch_bounds__(64 * NW, SF_SK_WAVES) jacobi_sk_kernel(Geom g, JacobiArgs<T, NF> A, int kb, int ke,
                                                                          SkMap m) {
     // Every sweep level loses one CELL of validity per side in i, so after S levels ceil(S / WL) lanes per side hold
@@ -1413,6 +1511,7 @@ __global__ void __launch_bounds__(64 * NW, SF_SK_WAVES) jacobi_sk_kernel(Geom g,
     const T* __restrict__ x = A.x[0];
     const T* __restrict__ x0 = A.x0[0];
     T* __restrict__ xn = A.xn[0];
+    T* __restrict__ x0out = FIRST == 2 ? A.x0out[0] : A.xn[0];
     int b = A.b[0];
 #pragma unroll
     for (int ff = 1; ff < NF; ++ff)
@@ -1455,14 +1554,14 @@ __global__ void __launch_bounds__(64 * NW, SF_SK_WAVES) jacobi_sk_kernel(Geom g,
     const int fb_hi = nvec == 1 ? fhi : (int)__umulhi((unsigned)fhi, m.nvec_magic);
     const bool rowend = fb_lo != fb_hi || flo - fb_lo * nvec == 0 || fhi - fb_hi * nvec == nvec - 1;
     if (jwall)
-        jsk_march<T, WL, NT, S, TJ, NW, true, ISH, true>(g, sh, rowb, rowst, x, x0, xn, k0, k1, a, inv, sx, sy, sz, jrow0,
-                                                         wave, lane, first_vec, last_vec);
+        jsk_march<T, WL, NT, S, TJ, NW, true, ISH, true, FIRST>(g, sh, rowb, rowst, x, x0, xn, k0, k1, a, inv, sx, sy, sz, jrow0,
+                                                         wave, lane, first_vec, last_vec, x0out, A.dt);
     else if (rowend)
-        jsk_march<T, WL, NT, S, TJ, NW, false, ISH, true>(g, sh, rowb, rowst, x, x0, xn, k0, k1, a, inv, sx, sy, sz, jrow0,
-                                                          wave, lane, first_vec, last_vec);
+        jsk_march<T, WL, NT, S, TJ, NW, false, ISH, true, FIRST>(g, sh, rowb, rowst, x, x0, xn, k0, k1, a, inv, sx, sy, sz, jrow0,
+                                                          wave, lane, first_vec, last_vec, x0out, A.dt);
     else
-        jsk_march<T, WL, NT, S, TJ, NW, false, ISH, false>(g, sh, rowb, rowst, x, x0, xn, k0, k1, a, inv, sx, sy, sz, jrow0,
-                                                           wave, lane, first_vec, last_vec);
+        jsk_march<T, WL, NT, S, TJ, NW, false, ISH, false, FIRST>(g, sh, rowb, rowst, x, x0, xn, k0, k1, a, inv, sx, sy, sz, jrow0,
+                                                           wave, lane, first_vec, last_vec, x0out, A.dt);
 }
 
 // LDS-staged, k-marching form of the two-sweep kernel (2.5-D temporal blocking).

@@ -130,7 +130,8 @@ def test_lin_solve(N, K, b, dtype, march_mode):
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "f64"])
-@pytest.mark.parametrize("N,K,b", [(100, 4, 1), (108, 5, 2), (20, 6, 3), (324, 4, 0), (408, 2, 1), (516, 2, 3)])
+@pytest.mark.parametrize("N,K,b", [(100, 4, 1), (108, 5, 2), (20, 6, 3), (324, 4, 0), (408, 2, 1), (516, 2, 3),
+                                   (100, 9, 2), (44, 11, 3), (324, 8, 1), (200, 7, 0)])
 def test_lin_solve_rows_that_straddle_waves(N, K, b, dtype, march_mode):
     """Row widths that are not a power of two, and rows wider than two waves (up to 258 vectors here): the fused
     kernel's overlapped mapping packs the (row pair, vector) items of a plane pair into 60-lane windows, so rows
@@ -200,7 +201,7 @@ def test_advect_lds_path(N, b, mode, dtype, monkeypatch):
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "f64"])
-@pytest.mark.parametrize("N,K", [(1, 2), (3, 3), (8, 4), (17, 5), (32, 6)])
+@pytest.mark.parametrize("N,K", [(1, 2), (3, 3), (8, 4), (17, 5), (32, 6), (36, 9), (20, 12), (100, 8)])
 def test_project(N, K, dtype, march_mode):
     f = rand_fields(N, dtype, 7)
     with make(N, dtype, K=K) as fs:
@@ -599,7 +600,8 @@ def test_snapshot_is_a_consistent_async_copy(P):
                                           (128, 7, np.float32, 1), (136, 4, np.float32, 1), (8, 4, np.float32, 1),
                                           (6, 1, np.float32, 1), (256, 4, np.float32, 1), (64, 6, np.float32, 4),
                                           (128, 20, np.float32, 2), (160, 6, np.float32, 4), (64, 5, np.float64, 2),
-                                          (16, 4, np.float32, 8), (16, 4, np.float32, 4)])
+                                          (16, 4, np.float32, 8), (16, 4, np.float32, 4), (36, 9, np.float32, 1),
+                                          (52, 12, np.float64, 1), (100, 8, np.float32, 1), (200, 7, np.float32, 1)])
 def test_bound_sources(N, K, dtype, P, fuse, monkeypatch, march_mode):
     """sf_bind_sources == copying the user slots into u0/v0/w0/dens0 before every step, bit for bit — with add_source
     folded into the first sweep pair of diffuse (SF_FUSE_SRC=1, single slab) and as a separate pass."""

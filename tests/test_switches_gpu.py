@@ -12,7 +12,8 @@ pytestmark = pytest.mark.gpu
 SWITCHES = [
     {},                             # defaults (three-sweep marching kernel on one slab, two-sweep on slab interiors)
     {"SF_MARCH": "0"},              # register-blocked pair kernel everywhere
-    {"SF_SK_S": "2"},               # marching kernel limited to two sweeps per pass
+    {"SF_SK_S": "2"}, {"SF_SK_S": "3"},  # marching kernel limited to two / three sweeps per pass
+    {"SF_SK_FIRST": "0"},           # first pass of a solve through the register-blocked pair kernel
     {"SF_FUSE2": "0"},              # single sweeps, one ghost plane
     {"SF_OVL": "0"}, {"SF_OVL": "2"},
     {"SF_TRAP": "0"}, {"SF_TRAP": "2"}, {"SF_TRAP": "5"},
@@ -54,7 +55,7 @@ def test_switch_settings_against_the_oracle(env, monkeypatch):
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     monkeypatch.setenv("SF_MARCH_MINCELLS_K", "100")  # let the marching kernel take these small grids too
-    for N, P, K, steps, transport in ((64, 1, 7, 2, "copy"), (64, 4, 6, 1, "copy"), (96, 2, 11, 1, "rccl-self"),
+    for N, P, K, steps, transport in ((64, 1, 7, 2, "copy"), (72, 1, 20, 1, "copy"), (64, 4, 6, 1, "copy"), (96, 2, 11, 1, "rccl-self"),
                                       (96, 3, 20, 1, "copy")):
         got, want = run_case(N, P, K, steps, transport)
         for n in got:
