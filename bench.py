@@ -16,7 +16,7 @@ one-GPU denominator (`single_gpu`) and `speedup`. `--weak` keeps ~256^3 cells pe
 docs/SPEC.md §5, resident in HBM before the timed region starts.
 
 Rank 0 prints ONE JSON line. Besides the contract fields it carries
-  roofline                : the dominant kernel (fused Jacobi sweeps of lin_solve) at 512^3 — the working set is far
+  roofline                : the dominant kernel (four fused Jacobi sweeps of lin_solve per launch) at 512^3 — the working set is far
                             beyond the 256 MiB Infinity Cache, so `achieved` is a statement about HBM — timed with
                             HIP events on the launch stream; `traffic` = counter-measured bytes per launch with its
                             provenance (a committed PMC pass: bench.py cannot run rocprofv3 on itself)
@@ -114,11 +114,12 @@ def words_per_cell_step(K):
 
 
 def time_lin_solve(S, N, dtype, K, reps, device):
-    """Duration of the Jacobi launches of lin_solve at size N (NF = 1), HIP events on the context's compute stream.
-    A K-sweep solve is one first launch of two fused sweeps (its iterate is caller data: the pair kernel that reads
-    the i-shell from memory) followed by launches of the dominant kernel, which fuses up to three sweeps
-    (sf_lin_solve_launches tells how many launches a solve issues). Timed: lin_solve(K) and lin_solve(2); the dominant
-    kernel's launches are the difference. Returns a dict (all times in microseconds)."""
+    """Duration of the dominant Jacobi launch of lin_solve at size N (NF = 1), HIP events on the context's compute
+    stream. A K-sweep solve is a sequence of fused launches (sf_lin_solve_launches says how many): with the k-marching
+    kernel K = 20 is five launches of four sweeps — the first reads caller data on the i-shell, the last writes it, the
+    three in between are the plain dominant launch. Timed: lin_solve(K) and lin_solve(K - d) for the d in {8, 6, 4} that
+    removes exactly two launches from the middle; the dominant launch is half the difference, d / 2 sweeps each.
+    Returns a dict (all times in microseconds)."""
     with S.FluidSolver(N, dtype=dtype, iters=K, device=device) as fs:
         rng = np.random.RandomState(1)
         plane = rng.standard_normal((1, N + 2, N + 2)).astype(fs.np_dtype)
@@ -127,7 +128,7 @@ def time_lin_solve(S, N, dtype, K, reps, device):
             fs.upload_planes("dens0", k, plane * (0.5 - 0.001 * k))
         a, c = 0.3, 1 + 6 * 0.3
         launches = fs.lin_solve_launches(K)
-        first = fs.lin_solve_launches(2)  # 1 where sweep pairs are fused
+        d = next((d for d in (8, 6, 4) if K - d >= 2 and launches - fs.lin_solve_launches(K - d) == 2), 0)
         fs.lin_solve(0, "dens", "dens0", a, c, K)  # warm-up
         fs.sync()
         tk, t2 = [], []
@@ -135,15 +136,14 @@ def time_lin_solve(S, N, dtype, K, reps, device):
             fs.timer_start()
             fs.lin_solve(0, "dens", "dens0", a, c, K)
             tk.append(fs.timer_stop() * 1e3)
-            fs.timer_start()
-            fs.lin_solve(0, "dens", "dens0", a, c, 2)
-            t2.append(fs.timer_stop() * 1e3)
+            if d:
+                fs.timer_start()
+                fs.lin_solve(0, "dens", "dens0", a, c, K - d)
+                t2.append(fs.timer_stop() * 1e3)
         fs.sync()
-        rest = launches - first
-        dom = [(x - y) / rest for x, y in zip(tk, t2)] if rest > 0 else [x / launches for x in tk]
+        dom = [(x - y) / 2 for x, y in zip(tk, t2)] if d else [x / launches for x in tk]
         return {"us_per_launch": float(np.mean(dom)), "us_per_launch_min": float(np.min(dom)),
-                "sweeps_per_launch": (K - 2) / rest if rest > 0 else K / launches,
-                "us_first_launch": float(np.mean(t2)) / max(first, 1), "launches_per_solve": launches,
+                "sweeps_per_launch": d / 2 if d else K / launches, "launches_per_solve": launches,
                 "us_per_sweep_whole_solve": float(np.mean(tk)) / K}
 
 
@@ -330,15 +330,17 @@ def main():
             us = max(r["us_per_launch"], 1e-9)
             tr = traffic.get(f"jacobi_{args.dtype}_{n}")
             e = {"bound": "hbm",
-                 "kernel": ("jacobi_sk_kernel<T,1,*,S=3>: three fused lin_solve sweeps + set_bnd per launch (k-marching, LDS "
+                 "kernel": ("jacobi_sk_kernel<T,1,*,S=4>: four fused lin_solve sweeps + set_bnd per launch (k-marching, LDS "
+                            "halo exchange)" if spl > 3.5 else
+                            "jacobi_sk_kernel<T,1,*,S=3>: three fused lin_solve sweeps + set_bnd per launch (k-marching, LDS "
                             "halo exchange)" if spl > 2.5 else
                             "two fused lin_solve sweeps + set_bnd per launch" if spl > 1.5 else
                             "jacobi_rb_kernel<T,1,*>: one lin_solve sweep + set_bnd per launch"),
                  "achieved": alg / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                  "frac": alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, "grid": n, "us_per_launch": us,
                  "us_per_launch_min": r["us_per_launch_min"], "sweeps_per_launch": spl,
-                 "algorithmic_bytes_per_launch": alg, "us_first_launch_of_a_solve": r["us_first_launch"],
-                 "launches_per_solve": r["launches_per_solve"], "us_per_sweep_whole_solve": r["us_per_sweep_whole_solve"]}
+                 "algorithmic_bytes_per_launch": alg, "launches_per_solve": r["launches_per_solve"],
+                 "us_per_sweep_whole_solve": r["us_per_sweep_whole_solve"]}
             if tr:
                 e["traffic"] = tr["bytes_per_launch"]
                 e["frac_traffic"] = tr["bytes_per_launch"] / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS

@@ -168,16 +168,19 @@ public:
         // and exchange one plane per sweep
         const bool fusable = env_int("SF_FUSE2", 1) != 0 && env_int("SF_JACOBI", 2) != 0 && N_ % W == 0 &&
                              N_ / W <= env_int("SF_FUSE_MAXVEC", 512);
-        G_ = (P_ > 1 && nzl_ >= 2 && fusable && env_int("SF_GHOST", 3) >= 2) ? 2 : 1;
-        // three ghost planes where the three-sweep marching kernel will run on the slab interiors (one exchange per
-        // three sweeps): the interior launch [G+3, G+nzl-3) must be long and large enough for that kernel
+        G_ = (P_ > 1 && nzl_ >= 2 && fusable && env_int("SF_GHOST", 4) >= 2) ? 2 : 1;
+        // three / four ghost planes where the marching kernel will run three / four sweeps per pass on the slab
+        // interiors (one exchange per pass): the interior launch [2G, nzl) must be long and large enough for it
         {
             const long min_cells = (long)env_int("SF_MARCH_MINCELLS_K", 6000) * 1000L;
-            const int interior = nzl_ - 6;
-            if (G_ == 2 && env_int("SF_GHOST", 3) >= 3 && env_int("SF_MARCH", 1) != 0 && env_int("SF_SK_S", 3) >= 3 &&
-                env_int("SF_SPLIT", 1) != 0 && interior >= env_int("SF_MARCH_MINP", 12) &&
-                (long)N_ * N_ * interior >= min_cells)
-                G_ = 3;
+            const int ghost_max = env_int("SF_GHOST", 4), smax = env_int("SF_SK_S", 4);
+            for (int gs = 3; gs <= 4; ++gs) {  // S = gs sweeps per exchange need gs ghost planes
+                const int interior = nzl_ - 2 * gs;
+                if (G_ == gs - 1 && ghost_max >= gs && env_int("SF_MARCH", 1) != 0 && smax >= gs &&
+                    env_int("SF_SPLIT", 1) != 0 && interior >= env_int("SF_MARCH_MINP", 12) &&
+                    (long)N_ * N_ * interior >= min_cells)
+                    G_ = gs;
+            }
         }
         nplanes_ = nzl_ + 2 * G_;
         field_elems_ = plane_ * nplanes_ + 256;  // slack so whole-vector accesses never leave the buffer
@@ -1543,8 +1546,10 @@ private:
     // May the FIRST pass of a K-sweep solve go through the marching kernel? Undecomposed grid, four-sweep launches
     // enabled, a grid the kernel takes, and sweeps left over afterwards (no i-shell-writing variant of a first pass).
     bool sk_first_ok(int K) const {
-        return sk_first_ && march_k_ != 0 && sk_s_ >= 4 && P_ == 1 && can_fuse2() && ishell_skip_ && K >= 7 &&
-               nzl_ >= march_min_planes_ && (long)N_ * N_ * nzl_ >= march_min_cells_;
+        if (!(sk_first_ && march_k_ != 0 && sk_s_ >= 4 && can_fuse2() && ishell_skip_ && K >= 7)) return false;
+        if (P_ == 1) return nzl_ >= march_min_planes_ && (long)N_ * N_ * nzl_ >= march_min_cells_;
+        const int interior = nzl_ - 8;  // slabs: four ghost planes and an interior launch the kernel takes
+        return G_ >= 4 && split_enabled_ && interior >= march_min_planes_ && (long)N_ * N_ * interior >= march_min_cells_;
     }
 
     template <int NF, int S>
@@ -1646,22 +1651,23 @@ private:
         if (it == 0 && !continued && sk_first_ok(K)) return 4;
         bool marching = pair && (it > 0 || continued) && march_k_ != 0 && sk_s_ >= 3 && left >= 3;
         if (marching && P_ == 1) marching = can_sk(nzl_, false);
-        if (marching && P_ > 1) {
-            // decomposed: three ghost planes, the two-stream schedule, and an interior launch [G+3+extra, ...) the
-            // marching kernel takes (the boundary launch always goes through it: there is no other three-sweep kernel)
-            const int interior = nzl_ - 2 * (3 + extra);
-            marching = G_ == 3 && split_enabled_ && interior >= march_min_planes_ &&
-                       (long)N_ * N_ * interior >= march_min_cells_;
-        }
-        // four sweeps per pass on an undecomposed grid (a slab boundary would need four ghost planes); remainders of
-        // 5 and 6 go as 3 + 2 and 3 + 3; without four-sweep launches a remainder of 4 goes as 2 + 2
-        if (marching && P_ == 1 && sk_s_ >= 4 && left >= 4 && left != 5 && left != 6) return 4;
-        if (marching && left != 4) return 3;
+        // S sweeps per pass need S ghost planes on a decomposed grid, the two-stream schedule, and an interior launch
+        // [G+S+extra, ...) the marching kernel takes (the boundary launch always goes through it: there is no other
+        // kernel of that depth)
+        auto slab_ok = [&](int S) {
+            const int interior = nzl_ - 2 * (S + extra);
+            return P_ == 1 || (G_ >= S && split_enabled_ && interior >= march_min_planes_ &&
+                               (long)N_ * N_ * interior >= march_min_cells_);
+        };
+        // four sweeps per pass; remainders of 5 and 6 go as 3 + 2 and 3 + 3; without four-sweep launches a remainder of
+        // 4 goes as 2 + 2
+        if (marching && sk_s_ >= 4 && left >= 4 && left != 5 && left != 6 && slab_ok(4)) return 4;
+        if (marching && left != 4 && slab_ok(3)) return 3;
         return pair ? 2 : 1;
     }
     // boundary depth of a two-sweep launch: the register-blocked pair kernel works on plane pairs, and a plane block
     // must not straddle the split of a boundary launch, so with three ghost planes it takes four planes per side
-    int pair_depth() const { return G_ == 3 ? 4 : 2; }
+    int pair_depth() const { return G_ >= 3 ? 4 : 2; }
 
     // K Jacobi sweeps on NF fields at once; scratch buffers are swapped into the slots.
     template <int NF>
@@ -1696,9 +1702,11 @@ private:
         // j-1) feeds the halo exchange. Every trap_m_ pairs the interior snaps back and waits for the boundary once.
         // Same arithmetic on every plane whichever launch computes it: results do not change.
         // With S sweeps per launch the growth is S planes per side: if interior launch j-1 started D planes into the
-        // slab, launch j starts D + S_j planes in (S_j = its sweeps), so it reads only what launch j-1 wrote; its
-        // boundary launch takes those D + S_j planes per side.
-        int tj = 0, dprev = 0;
+        // slab, launch j starts D + max(S_j, S_{j-1}) planes in (S_j = its sweeps). S_j: it reads only what interior
+        // launch j-1 wrote. S_{j-1}: it WRITES the buffer that was the input of launch j-1, which boundary launch j-1
+        // (another stream, possibly still running) reads up to D + S_{j-1} planes in — a four-sweep launch followed
+        // by a three-sweep one raced there until this was the maximum. Its boundary launch takes those planes.
+        int tj = 0, dprev = 0, sprev = 0;
         int it = 0;
         while (it < K) {
             const bool pair = can_fuse2() && it + 2 <= K;
@@ -1710,14 +1718,15 @@ private:
             int extra = 0;
             {
                 // does this launch continue the trapezoid block?
-                const int d = dprev + step;  // where its interior launch would start
+                const int d = dprev + std::max(step, sprev);  // where its interior launch would start
                 bool cont = pair && P_ > 1 && G_ >= 2 && trap_m_ > 1 && tj > 0 && tj < trap_m_ && d >= depth0 &&
                             nzl_ > 2 * d + 2;
-                if (cont && step == 3 && sweeps_in_launch(it, K, continued, d - depth0) != 3) cont = false;
+                if (cont && step >= 3 && sweeps_in_launch(it, K, continued, d - depth0) != step) cont = false;
                 if (cont && step == 2 && (d & 1)) cont = false;  // plane pairs: even boundary depth
                 if (!cont) tj = 0;
                 extra = cont ? d - depth0 : 0;
                 dprev = depth0 + extra;
+                sprev = step;
             }
             const bool triple = step >= 3;  // three or four sweeps: the marching kernel
             trap_extra_ = extra;
@@ -1749,6 +1758,32 @@ private:
         }
         trap_extra_ = 0;
         x_is_zero_ = false;
+    }
+
+    // Right-hand side x + dt*src of a folded add_source on the G-1 ghost planes next to the slab on either side (an
+    // S-sweep launch evaluates its first S-1 levels there and needs x0 for them; the source pass itself stores it on the
+    // planes it computes). It reads ghost planes of x, so it must follow the last halo: on the boundary stream when
+    // for_planes ran its two-stream schedule with that boundary depth (bs waits for every halo and the next boundary
+    // launch follows in stream order), on the compute stream otherwise (for_planes has just joined it).
+    template <int NF>
+    void rhs_on_ghost_planes(const int (&x)[NF], const int (&x0)[NF], const int (&src)[NF], int depth) {
+        if (P_ == 1) return;
+        const bool two = split_enabled_ && nzl_ > 2 * std::max(depth, G_);
+        for (Slab& sl : slabs_) {
+            sfk::RhsPlanesArgs<T, NF> R;
+            for (int f = 0; f < NF; ++f) {
+                R.out[f] = sl.field[x0[f]];
+                R.a[f] = sl.field[x[f]];
+                R.s[f] = sl.field[src[f]];
+            }
+            R.dt = dt_;
+            R.off[0] = (long)1 * plane_;            // planes 1 .. G-1
+            R.off[1] = (long)(G_ + nzl_) * plane_;  // planes G+nzl .. G+nzl+G-2
+            R.nvec = (long)(G_ - 1) * plane_ / W;
+            hipLaunchKernelGGL((sfk::rhs_planes_kernel<T, NF>), dim3((unsigned)ceil_div(R.nvec, 256L), 2), dim3(256), 0,
+                               two ? sl.bs : sl.cs, R);
+        }
+        SF_HIP(hipGetLastError());
     }
 
     // diffuse with add_source folded in (sources bound to resident slots): replaces
@@ -1801,8 +1836,10 @@ private:
                 A.dt = dt_;
                 launch_sk_first<NF>(sl, A, kb, ke, 2);
             }, 4, true);
+            rhs_on_ghost_planes<NF>(x, x0, src, 4);
             for (Slab& sl : slabs_)
                 for (int f = 0; f < NF; ++f) std::swap(sl.field[x[f]], sl.scratch[f]);
+            exchange<NF>(x);
             op_lin_solve<NF>(x, x0, b, a, c, K - 4, false, true);
             return;
         }
@@ -1820,29 +1857,7 @@ private:
             A.dt = dt_;
             launch_jacobi2<NF, true>(sl, A, kb, ke, true, K == 2);
         }, pair_depth(), true);
-        if (P_ > 1) {
-            // right-hand side on the G-1 ghost planes next to the slab on either side (an S-sweep launch evaluates its
-            // first S-1 levels there and needs x0 for them). It reads ghost planes of x, so it must follow the
-            // last halo: on the boundary stream when for_planes ran its two-stream schedule (bs waits for every halo
-            // and the next boundary launch follows in stream order), on the compute stream otherwise (for_planes
-            // has just joined it)
-            const bool two = split_enabled_ && nzl_ > 2 * std::max(pair_depth(), G_);
-            for (Slab& sl : slabs_) {
-                sfk::RhsPlanesArgs<T, NF> R;
-                for (int f = 0; f < NF; ++f) {
-                    R.out[f] = sl.field[x0[f]];
-                    R.a[f] = sl.field[x[f]];
-                    R.s[f] = sl.field[src[f]];
-                }
-                R.dt = dt_;
-                R.off[0] = (long)1 * plane_;  // planes 1 .. G-1
-                R.off[1] = (long)(G_ + nzl_) * plane_;  // planes G+nzl .. G+nzl+G-2
-                R.nvec = (long)(G_ - 1) * plane_ / W;
-                hipLaunchKernelGGL((sfk::rhs_planes_kernel<T, NF>), dim3((unsigned)ceil_div(R.nvec, 256L), 2), dim3(256), 0,
-                                   two ? sl.bs : sl.cs, R);
-            }
-            SF_HIP(hipGetLastError());
-        }
+        rhs_on_ghost_planes<NF>(x, x0, src, pair_depth());
         for (Slab& sl : slabs_)
             for (int f = 0; f < NF; ++f) std::swap(sl.field[x[f]], sl.scratch[f]);
         exchange<NF>(x);

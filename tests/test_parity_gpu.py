@@ -328,7 +328,9 @@ def test_slabs_stress_against_single_slab(N, P, K, prio, transport, monkeypatch)
 
 
 @pytest.mark.parametrize("N,P,K,trap", [(128, 2, 20, "5"), (128, 4, 20, "3"), (160, 4, 12, "10"), (320, 2, 20, "5"),
-                                        (128, 2, 20, "0"), (64, 2, 9, "4")])
+                                        (128, 2, 20, "0"), (64, 2, 9, "4"),
+                                        # launches of different depth inside one trapezoid block (4 then 3, 4 3 2, ...)
+                                        (128, 2, 7, "5"), (128, 2, 9, "5"), (96, 2, 11, "8"), (160, 2, 23, "8")])
 @pytest.mark.parametrize("transport", TRANSPORTS)
 def test_slabs_trapezoid_schedule(N, P, K, trap, transport, monkeypatch, march_mode):
     """lin_solve on a decomposed grid: the boundary launch grows by two planes per pair so that consecutive interior

@@ -19,7 +19,7 @@ SWITCHES = [
     {"SF_TRAP": "0"}, {"SF_TRAP": "2"}, {"SF_TRAP": "5"},
     {"SF_HALO_STREAM": "1"}, {"SF_HALO_STREAM": "2"},
     {"SF_SPLIT_FIELDS": "0"}, {"SF_SPLIT_FIELDS": "2"},
-    {"SF_GHOST": "1"}, {"SF_GHOST": "2"},
+    {"SF_GHOST": "1"}, {"SF_GHOST": "2"}, {"SF_GHOST": "3"},
     {"SF_FUSE_SRC": "0"}, {"SF_ZERO_SKIP": "0"}, {"SF_SPLIT": "0"},
     {"SF_MARCH": "0", "SF_TRAP": "3", "SF_HALO_STREAM": "2", "SF_SPLIT_FIELDS": "0"},
 ]

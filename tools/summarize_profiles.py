@@ -53,8 +53,9 @@ traffic = {}
 lines = [f"# Jacobi lin_solve — rocprofv3 PMC summary ({tag})", "",
          "Separate `--pmc` passes (FETCH_SIZE | WRITE_SIZE | TCC_HIT/MISS | TCP_TCC_READ_REQ, TCC_EA0_RD/WRREQ) plus a",
          "`--kernel-trace --stats` pass of `SF_SWEEP_K=20 python3 tools/jacobi_sweep.py N`: one 20-sweep solve after a",
-         "2-sweep warm-up = 1 launch of the register-blocked pair kernel (`jacobi2_kernel`, the first pass of a solve) +",
-         "6 launches of the three-sweep marching kernel (`jacobi_sk_kernel<.., S = 3, ..>`; the last one writes the i-shell).",
+         "2-sweep warm-up (one launch of the register-blocked pair kernel `jacobi2_kernel`) = 5 launches of the four-sweep",
+         "marching kernel `jacobi_sk_kernel<T, NF, WL, NT, S = 4, TJ, NW, ISH, FIRST>`: the first reads caller data on the",
+         "i-shell (FIRST = 1), three plain ones, the last writes the i-shell (ISH = true).",
          "FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 128-byte requests as 64 B, so read bytes =",
          "2 x FETCH_SIZE (MI355X_MICROARCH.md, HBM). `alg` = 3 words x N^3 x sweeps of the launch (SURVEY.md §8d).", ""]
 for N in (256, 512):
@@ -86,7 +87,8 @@ for N in (256, 512):
             continue
         lines.append(f"| `{k[:72]}` | {S} | {calls} | {ns / 1e3:.1f} | {rd / 1e6:.1f} | {wr / 1e6:.1f} | {(rd + wr) / alg:.3f} | "
                      f"{(rd + wr) / ns / 1e3:.2f} | {alg / ns / 1e3:.2f} ({alg / ns / 8e3:.2f}) | {req / 1e6:.2f} | {hit / max(hit + miss, 1):.3f} |")
-        if S == 3 and "false>" in k[-8:] or (S == 3 and f"jacobi_f32_{N}" not in traffic):
+        plain = re.search(r"false(, 0)?>$", k.strip()) is not None  # no i-shell writes, not a first pass
+        if S == 4 and (plain or f"jacobi_f32_{N}" not in traffic):
             traffic[f"jacobi_f32_{N}"] = {"bytes_per_launch": rd + wr, "kernel": k[:80], "tag": tag,
                                           "source": f"profiles/{tag}_jacobi_pmc.md (FETCH_SIZE x2 + WRITE_SIZE, separate "
                                                     "rocprofv3 --pmc passes of tools/jacobi_sweep.py)",
@@ -99,7 +101,7 @@ print("\n".join(lines))
 # ---- instruction-issue picture: marching kernel against the round-1 pair kernel -------------------------------
 issue = [f"# Jacobi kernels — instruction-issue counters ({tag})", "",
          "`tools/collect_profiles.sh`: separate `rocprofv3 --pmc` passes over `SF_SWEEP_K=20 python3 tools/jacobi_sweep.py N`,",
-         "with the default build (three-sweep marching kernel `jacobi_sk_kernel<..,3,6,8,..>` after the first pair) and with",
+         "with the default build (four-sweep marching kernel `jacobi_sk_kernel<..,4,4,8,..>`) and with",
          "`SF_MARCH=0` (the register-blocked pair kernel `jacobi2_kernel` of round 1 for every pass). SQ_INSTS_* are sums over",
          "all waves; *_CYCLES / ACTIVE / WAIT are in quad-cycles (x4 clocks). `per cell-sweep` divides by N^3 x sweeps of the",
          "launch — the figure that can be compared across kernels that fuse a different number of sweeps.", ""]
