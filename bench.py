@@ -114,12 +114,11 @@ def words_per_cell_step(K):
 
 
 def time_lin_solve(S, N, dtype, K, reps, device):
-    """Duration of the dominant Jacobi launch of lin_solve at size N (NF = 1), HIP events on the context's compute
-    stream. A K-sweep solve is a sequence of fused launches (sf_lin_solve_launches says how many): with the k-marching
-    kernel K = 20 is five launches of four sweeps — the first reads caller data on the i-shell, the last writes it, the
-    three in between are the plain dominant launch. Timed: lin_solve(K) and lin_solve(K - d) for the d in {8, 6, 4} that
-    removes exactly two launches from the middle; the dominant launch is half the difference, d / 2 sweeps each.
-    Returns a dict (all times in microseconds)."""
+    """Average duration of ONE Jacobi launch of lin_solve at size N (NF = 1): HIP events on the context's compute stream
+    around lin_solve(K), divided by the number of launches it issues (sf_lin_solve_launches). With the k-marching kernel
+    a K = 20 solve is five launches of four fused sweeps each (the first reads caller data on the i-shell, the last
+    writes the i-shell: same kernel, three template variants — the rocprofv3 kernel-trace averages of the three,
+    weighted 1 : 3 : 1, are what this number must agree with). Returns a dict (times in microseconds)."""
     with S.FluidSolver(N, dtype=dtype, iters=K, device=device) as fs:
         rng = np.random.RandomState(1)
         plane = rng.standard_normal((1, N + 2, N + 2)).astype(fs.np_dtype)
@@ -128,23 +127,17 @@ def time_lin_solve(S, N, dtype, K, reps, device):
             fs.upload_planes("dens0", k, plane * (0.5 - 0.001 * k))
         a, c = 0.3, 1 + 6 * 0.3
         launches = fs.lin_solve_launches(K)
-        d = next((d for d in (8, 6, 4) if K - d >= 2 and launches - fs.lin_solve_launches(K - d) == 2), 0)
         fs.lin_solve(0, "dens", "dens0", a, c, K)  # warm-up
         fs.sync()
-        tk, t2 = [], []
+        per = []
         for _ in range(reps):
             fs.timer_start()
             fs.lin_solve(0, "dens", "dens0", a, c, K)
-            tk.append(fs.timer_stop() * 1e3)
-            if d:
-                fs.timer_start()
-                fs.lin_solve(0, "dens", "dens0", a, c, K - d)
-                t2.append(fs.timer_stop() * 1e3)
+            per.append(fs.timer_stop() * 1e3 / launches)
         fs.sync()
-        dom = [(x - y) / 2 for x, y in zip(tk, t2)] if d else [x / launches for x in tk]
-        return {"us_per_launch": float(np.mean(dom)), "us_per_launch_min": float(np.min(dom)),
-                "sweeps_per_launch": d / 2 if d else K / launches, "launches_per_solve": launches,
-                "us_per_sweep_whole_solve": float(np.mean(tk)) / K}
+        return {"us_per_launch": float(np.mean(per)), "us_per_launch_min": float(np.min(per)),
+                "sweeps_per_launch": K / launches, "launches_per_solve": launches,
+                "us_per_sweep_whole_solve": float(np.mean(per)) * launches / K}
 
 
 def cpu_baseline(N, K, dtype, steps, dt, diff, visc):

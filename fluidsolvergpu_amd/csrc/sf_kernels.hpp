@@ -1285,13 +1285,18 @@ __device__ __forceinline__ void jsk_step(const Geom& g, SkShared<T, WL, S, TJ, N
                 // hardware drops an out-of-range buffer store.
                 if constexpr (!WALLS) {
                     const unsigned offv = rowst[r];
-                    const unsigned offlo = (ISH && valid && first_vec) ? rowb[r] - (unsigned)sizeof(T) : OOB;
-                    const unsigned offhi = (ISH && valid && last_vec) ? rowb[r] + WL * (unsigned)sizeof(T) : OOB;
+                    // the i = 0 / N+1 shell cell of a row end: ONE store instruction per row serves whichever end the
+                    // lane sits at (a lane is never both: rows hold >= 2 vectors), and only workgroups that hold a
+                    // row end issue it at all. (The last pass of a solve still costs 25-35 % more than a plain one at
+                    // 512^3: N^2 x planes x 2 four-byte writes, each alone in its 128-byte line — cell 0 ends the line
+                    // before the row, cell N+1 starts the one after it when N % 32 == 0 — are partial writes to HBM.
+                    // Non-temporal, whole-32-byte-sector and all-lanes-in-range forms of this store measured the same.)
+                    constexpr bool SHELL = ISH && ROWEND;
+                    const unsigned offsh = (SHELL && valid && first_vec) ? rowb[r] - (unsigned)sizeof(T)
+                                           : ((SHELL && valid && last_vec) ? rowb[r] + WL * (unsigned)sizeof(T) : OOB);
+                    const T osh = first_vec ? o[0] : o[WL - 1];
                     buf_store<T, WL, NT>(rc, offv, o);
-                    if constexpr (ISH) {  // no j wall near this workgroup: only the i = 0 / N+1 cells of the row
-                        buf_store1<T>(rc, offlo, sx * o[0]);
-                        buf_store1<T>(rc, offhi, sx * o[WL - 1]);
-                    }
+                    if constexpr (SHELL) buf_store1<T>(rc, offsh, sx * osh);
                     // first / last plane of a wall slab (wave-uniform, one step per chunk end): the k face of this row
                     // and, with the i-shell, its two i-k edge cells — the expressions of emit_shells
                     const bool kslo = g.wall_lo && kg == 1, kshi = g.wall_hi && kg == N;
@@ -1300,22 +1305,16 @@ __device__ __forceinline__ void jsk_step(const Geom& g, SkShared<T, WL, S, TJ, N
                         VW t;
 #pragma unroll
                         for (int e = 0; e < WL; ++e) t[e] = sz * o[e];
-                        const T elo = half * (sz * o[0] + sx * o[0]), ehi = half * (sz * o[WL - 1] + sx * o[WL - 1]);
+                        const T esh = half * (sz * osh + sx * osh);  // the i-k edge cell of that row end
                         if (kslo) {
                             const __amdgpu_buffer_rsrc_t rk = plane_rsrc(po - g.plane);
                             buf_store<T, WL, false>(rk, offv, t);
-                            if constexpr (ISH) {
-                                buf_store1<T>(rk, offlo, elo);
-                                buf_store1<T>(rk, offhi, ehi);
-                            }
+                            if constexpr (SHELL) buf_store1<T>(rk, offsh, esh);
                         }
                         if (kshi) {
                             const __amdgpu_buffer_rsrc_t rk = plane_rsrc(po + g.plane);
                             buf_store<T, WL, false>(rk, offv, t);
-                            if constexpr (ISH) {
-                                buf_store1<T>(rk, offlo, elo);
-                                buf_store1<T>(rk, offhi, ehi);
-                            }
+                            if constexpr (SHELL) buf_store1<T>(rk, offsh, esh);
                         }
                     }
                 } else if (valid) {
