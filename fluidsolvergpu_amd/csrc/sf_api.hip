@@ -185,6 +185,12 @@ public:
         nplanes_ = nzl_ + 2 * G_;
         field_elems_ = plane_ * nplanes_ + 256;  // slack so whole-vector accesses never leave the buffer
         field_elems_ = (field_elems_ + W - 1) / W * W;
+        // Rows of padding before and after every field: the marching kernel addresses the rows of a workgroup's tile
+        // without clamping them into the plane (sfk::jsk_step), so the tile of the first j-block reaches up to three
+        // rows below the first plane and the tile of the last one up to NW x TJ rows beyond the last plane. Never
+        // stored to, and what is loaded there only feeds rows that are not stored.
+        pad_front_ = (sfk::SK_PAD_ROWS_FRONT * (long)px_ + 63) / 64 * 64;
+        pad_back_ = sfk::SK_PAD_ROWS_BACK * (long)px_;
 
         slabs_.resize(L_);
         for (int s = 0; s < L_; ++s) {
@@ -263,6 +269,7 @@ public:
         fuse2_ = env_int("SF_FUSE2", 1);
         kc2_ = env_int("SF_KC2", 32);
         advect_lds_ = env_int("SF_ADVECT_LDS", 0) != 0;
+        advect_row_ = env_int("SF_ADVECT_ROW", 1);
         zero_skip_ = env_int("SF_ZERO_SKIP", 1) != 0;
         fuse_maxvec_ = env_int("SF_FUSE_MAXVEC", 512);
         tx_override_ = env_int("SF_TX", 0);
@@ -287,6 +294,7 @@ public:
         sk_s_ = env_int("SF_SK_S", 4);
         sk_cfg_ = env_int("SF_SK_CFG", -1);  // tile shape: -1 automatic, 0..3 see SF_SK_CFGS
         sk_kc_ = env_int("SF_SK_KC", 0);
+        sk_linear_ = env_int("SF_SK_LINEAR", 0) != 0;
         sk_wgcu_ = env_int("SF_SK_WGCU", 0);
         sk_first_ = env_int("SF_SK_FIRST", 1) != 0;  // first pass of a solve through the marching kernel
         SF_HIP(hipDeviceSynchronize());
@@ -370,13 +378,10 @@ public:
         for (GraphEntry& e : graph_cache_) (void)hipGraphExecDestroy(e.exec);
         if (comm_) ncclCommDestroy(comm_);
         for (Slab& sl : slabs_) {
-            for (T*& f : sl.field)
-                if (f) (void)hipFree(f);
-            for (T*& f : sl.scratch)
-                if (f) (void)hipFree(f);
+            for (T*& f : sl.field) free_field(f);
+            for (T*& f : sl.scratch) free_field(f);
             if (sl.d_flag) (void)hipFree(sl.d_flag);
-            for (T*& f : sl.snap)
-                if (f) (void)hipFree(f);
+            for (T*& f : sl.snap) free_field(f);
             if (sl.os) (void)hipStreamDestroy(sl.os);
             if (sl.snap_done) (void)hipEventDestroy(sl.snap_done);
             if (sl.cs) (void)hipStreamDestroy(sl.cs);
@@ -921,12 +926,16 @@ private:
 
     T* alloc_field() {
         T* p = nullptr;
-        SF_HIP(hipMalloc(&p, (size_t)field_elems_ * sizeof(T)));
-        SF_HIP(hipMemset(p, 0, (size_t)field_elems_ * sizeof(T)));
+        const size_t total = (size_t)(pad_front_ + field_elems_ + pad_back_) * sizeof(T);
+        SF_HIP(hipMalloc(&p, total));
+        SF_HIP(hipMemset(p, 0, total));
         // hipMemset on device memory may return before the fill has run, and the context's streams are
         // non-blocking (they do not order against the null stream): wait here.
         SF_HIP(hipDeviceSynchronize());
-        return p;
+        return p + pad_front_;
+    }
+    void free_field(T* f) const {
+        if (f) (void)hipFree(f - pad_front_);
     }
     T* ensure(Slab& sl, int f) {
         if (!sl.field[f]) {
@@ -1469,7 +1478,8 @@ private:
         for (int c = 1; c <= max_chunks; ++c) {
             const int kc = ceil_div(np, c);
             const long total = (long)ncb * ceil_div(np, kc);
-            const double tm = (double)ceil_div(total, (long)num_cu_) * (kc + 2 * S - 2 + 2);
+            // (workgroups are dealt to the eight XCDs in turn; an XCD runs one per CU at a time)
+            const double tm = (double)ceil_div(ceil_div(total, 8L), (long)std::max(1, num_cu_ / 8)) * (kc + 2 * S - 2 + 2);
             if (best < 0 || tm < best * 0.999) {
                 best = tm;
                 nchunk = c;
@@ -1503,7 +1513,14 @@ private:
         }
         m.kc = split_ != INT_MAX ? split_ : ceil_div(np, nchunk);
         nchunk = ceil_div(np, m.kc);
-        const dim3 nb(8u, (unsigned)m.band, (unsigned)nchunk);
+        dim3 nb(8u, (unsigned)m.band, (unsigned)nchunk);
+        // (SF_SK_LINEAR=1: a launch of one round of workgroups deals its column blocks to the XCDs one by one instead
+        // of in bands — balanced to within one workgroup whatever the band size, but neighbours no longer share an
+        // L2: 256^3 63.6 vs 61.6 us per launch, so off unless asked for)
+        if ((long)m.ncb * nchunk <= (long)num_cu_ && sk_linear_) {
+            m.band = 0;
+            nb = dim3((unsigned)m.ncb, 1u, (unsigned)nchunk);
+        }
         if constexpr (FIRST != 0) {  // a first pass is never the last one (sk_first_ok)
             launch_k(sl, sfk::jacobi_sk_kernel<T, 1, WL, NT, S, TJ, NW, false, FIRST>, nb, 64u * NW, sl.geom, A, kb, ke, m);
         } else {
@@ -1520,7 +1537,9 @@ private:
     void launch_sk_first(Slab& sl, const sfk::JacobiArgs<T, NF>& A, int kb, int ke, int mode) {
         const bool nt = nt_mode_ == 1 ||
                         (nt_mode_ == 2 && (size_t)field_elems_ * sizeof(T) * 3 * NF > ((size_t)384 << 20));
-        constexpr int TJ0 = sizeof(T) == 4 ? 4 : 5;
+        // rows per wave: four; five in fp64 for the zero-iterate pass (no x ring to fill — the passes that read the
+        // caller's i-shell hold a ring of shell cells on top and spill at five)
+        constexpr int TJ0 = 4, TJ3 = sizeof(T) == 4 ? 4 : 5;
         for (int f = 0; f < NF; ++f) {
             sfk::JacobiArgs<T, 1> B;
             B.x[0] = A.x[f];
@@ -1538,8 +1557,8 @@ private:
                 if (nt) launch_sk_cfg<true, 4, TJ0, 8, 2>(sl, B, kb, ke, false);
                 else launch_sk_cfg<false, 4, TJ0, 8, 2>(sl, B, kb, ke, false);
             } else {
-                if (nt) launch_sk_cfg<true, 4, TJ0, 8, 3>(sl, B, kb, ke, false);
-                else launch_sk_cfg<false, 4, TJ0, 8, 3>(sl, B, kb, ke, false);
+                if (nt) launch_sk_cfg<true, 4, TJ3, 8, 3>(sl, B, kb, ke, false);
+                else launch_sk_cfg<false, 4, TJ3, 8, 3>(sl, B, kb, ke, false);
             }
         }
     }
@@ -1564,6 +1583,9 @@ private:
             B.b[0] = A.b[f];
             B.a = A.a;
             B.inv = A.inv;
+#ifndef SF_SK4_TJ
+#define SF_SK4_TJ 4  // rows per wave of the plain four-sweep launches in fp32 (fp64: five)
+#endif
 #ifndef SF_SK_CFGS
 #define SF_SK_CFGS 1  // bit q: instantiate configuration q (0: 6 rows x 8 waves, 1: 4 x 4, 2: 6 x 4, 3: 4 x 8)
 #endif
@@ -1593,9 +1615,14 @@ private:
                 }
             } else {
                 if constexpr ((SF_SK_CFGS & 1) != 0) {
-                    // four levels hold 21 planes of rows per lane: four rows per wave fit 256 registers in fp32 (five
-                    // spill: 256^3 27.6 vs 17.7 us/sweep), five in fp64 (one 8-byte cell per lane, no packed pairs)
-                    constexpr int TJ0 = S == 4 ? (sizeof(T) == 4 ? 4 : 5) : 6;
+                    // four levels hold 17 planes of rows per lane (x 3, x0 5, three intermediate levels x 3). Five
+                    // rows per wave fit 256 registers only just (and only with the row offsets re-derived per step
+                    // and the levels fenced off from each other), and buy nothing: the kernel is bound by the bytes a
+                    // CU requests per unit time, five rows request 6 % fewer per cell (32 of 40 tile rows stored
+                    // instead of 24 of 32) and issue worse — 446 vs 431 us at 512^3, 67.9 vs 66.1 at 256^3. (A spill of
+                    // nine registers in the wall workgroups alone doubled the launch at 256^3, where every workgroup
+                    // runs at once and the slowest one is the launch.)
+                    constexpr int TJ0 = S == 4 ? (sizeof(T) == 4 ? SF_SK4_TJ : 5) : 6;
                     if (nt)
                         launch_sk_cfg<true, S, TJ0, 8>(sl, B, kb, ke, last);
                     else
@@ -1899,7 +1926,15 @@ private:
             if (advect_lds_ && m.gx == 1 && lds <= 64 * 1024)
                 hipLaunchKernelGGL((sfk::advect_lds_kernel<T, NF>), dim3(nblocks), block, lds, sl.cur, sl.geom, A, kb,
                                    ke, m, rs);
-            else
+            else if (advect_row_ >= 2 || (advect_row_ == 1 && NF >= 2 && sizeof(T) == 4)) {
+                // one cell per lane, the i0+1 samples from the neighbour lane: the three velocity components in fp32
+                // (256^3 245 -> 176 us, 512^3 1628 -> 1217). One field: 79 -> 88 / 572 -> 662, fp64: 350 -> 399 /
+                // 2418 -> 2826 — the gather form stays there. SF_ADVECT_ROW=0 / 2: never / always.
+                const int wpr = ceil_div(N_, 64);
+                const long waves = (long)wpr * N_ * (ke - kb);
+                hipLaunchKernelGGL((sfk::advect_row_kernel<T, NF>), dim3((unsigned)ceil_div(waves, 4L)), dim3(256), 0,
+                                   sl.cur, sl.geom, A, kb, ke, wpr);
+            } else
                 hipLaunchKernelGGL((sfk::advect_kernel<T, NF>), dim3(nblocks), block, 0, sl.cur, sl.geom, A, kb, ke, m);
         }, 1, true, /*interior_reads_ghosts=*/true);  // a long back-trace may reach a ghost plane from any plane
         exchange<NF>(d);
@@ -1962,13 +1997,15 @@ private:
     T dt_{}, diff_{}, visc_{};
     int num_cu_ = 256;
     int nzl_ = 0, lead_ = 0, px_ = 0, nplanes_ = 0, kchunk_ = 0, jacobi_mode_ = 2, tx_override_ = 0, nt_mode_ = 2, rb_shape_ = 0;
+    int advect_row_ = 1;  // 0 gather form always, 1 one cell per lane for the three velocity components, 2 always
     bool ishell_skip_ = true, advect_lds_ = false, zero_skip_ = true, x_is_zero_ = false, fuse_src_ = true;
     int fuse2_ = 1, kc2_ = 32;
     int march_k_ = 1, march_min_planes_ = 12;
     long march_min_cells_ = 6000000, sk2_min_cells_ = 60000000;
     int sk_s_ = 4, sk_cfg_ = -1, sk_kc_ = 0, sk_wgcu_ = 0;
+    bool sk_linear_ = false;
     bool sk_first_ = true;
-    long plane_ = 0, field_elems_ = 0;
+    long plane_ = 0, field_elems_ = 0, pad_front_ = 0, pad_back_ = 0;
     std::vector<Slab> slabs_;
     ncclComm_t comm_ = nullptr;
     bool loopback_ = false, rccl_self_ = false;

@@ -85,7 +85,7 @@ __device__ __forceinline__ long row0(const Geom& g, int j, int kl) {
 // Store the nv valid cells of a W-wide vector starting at cell i0 of the row whose i=0 is at `r`.
 template <class T, int W>
 __device__ __forceinline__ void store_cells(T* __restrict__ f, long r, int i0, const T (&v)[W], int nv) {
-    if (nv == W) {
+    if (W == VecT<T>::W && nv == W) {  // (W < the 16-byte vector: cell by cell)
         typename VecT<T>::type o;
 #pragma unroll
         for (int e = 0; e < W; ++e) o[e] = v[e];
@@ -934,6 +934,15 @@ __global__ void __launch_bounds__(256, SF_J2_WAVES) jacobi2_kernel(Geom g, Jacob
 
 // Lane vector of the marching kernel (jacobi_sk_kernel below): WL cells = 8 bytes (two floats / one double) — half the
 // register state per lane of the 16-byte vectors used elsewhere, which is what lets two waves share a SIMD.
+// A buffer offset that is out of range of every plane resource under either reading of the range check (with or without
+// the instruction's scalar offset, at most a plane, added in): dropped stores, loads that return 0.
+constexpr unsigned SK_OOB = 0x80000000u;
+// Rows of padding the host allocates before / after every field for the marching kernel: the rows of a workgroup's tile
+// are addressed as (row 0 of the lane) + r rows, not clamped into the plane, so the first j-block reaches S-1 rows
+// below j = 0 and the last one up to NW x TJ - S - 2 rows beyond j = N+1 (of the first / last plane: elsewhere that is
+// the neighbouring plane). Nothing is stored there and what is loaded only feeds rows that are not stored.
+constexpr int SK_PAD_ROWS_FRONT = 4, SK_PAD_ROWS_BACK = 64;
+
 template <class T, int WL>
 struct LaneVec {
     typedef T type __attribute__((ext_vector_type(WL)));
@@ -945,51 +954,54 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t plane_rsrc(const void* base) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
 }
 template <class T, int WL>
-__device__ __forceinline__ typename LaneVec<T, WL>::type buf_load(__amdgpu_buffer_rsrc_t r, unsigned off) {
+__device__ __forceinline__ typename LaneVec<T, WL>::type buf_load(__amdgpu_buffer_rsrc_t r, unsigned off,
+                                                                  unsigned soff = 0) {
+    // soff: a wave-uniform byte offset added by the instruction itself (the `soffset` scalar operand)
     typedef typename LaneVec<T, WL>::type VW;
     constexpr int B = WL * (int)sizeof(T);
     static_assert(B == 4 || B == 8 || B == 16, "lane vector must be 4, 8 or 16 bytes");
     if constexpr (B == 4) {
-        return __builtin_bit_cast(VW, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+        return __builtin_bit_cast(VW, __builtin_amdgcn_raw_buffer_load_b32(r, off, soff, 0));
     } else if constexpr (B == 8) {
         typedef int I2 __attribute__((ext_vector_type(2)));
-        return __builtin_bit_cast(VW, (I2)__builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0));
+        return __builtin_bit_cast(VW, (I2)__builtin_amdgcn_raw_buffer_load_b64(r, off, soff, 0));
     } else {
         typedef int I4 __attribute__((ext_vector_type(4)));
-        return __builtin_bit_cast(VW, (I4)__builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+        return __builtin_bit_cast(VW, (I4)__builtin_amdgcn_raw_buffer_load_b128(r, off, soff, 0));
     }
 }
 template <class T, int WL, bool NT>
-__device__ __forceinline__ void buf_store(__amdgpu_buffer_rsrc_t r, unsigned off, typename LaneVec<T, WL>::type v) {
+__device__ __forceinline__ void buf_store(__amdgpu_buffer_rsrc_t r, unsigned off, typename LaneVec<T, WL>::type v,
+                                          unsigned soff = 0) {
     constexpr int B = WL * (int)sizeof(T);
     constexpr int AUX = NT ? 2 : 0;  // nt
     if constexpr (B == 4) {
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, off, 0, AUX);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, off, soff, AUX);
     } else if constexpr (B == 8) {
         typedef int I2 __attribute__((ext_vector_type(2)));
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(I2, v), r, off, 0, AUX);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(I2, v), r, off, soff, AUX);
     } else {
         typedef int I4 __attribute__((ext_vector_type(4)));
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(I4, v), r, off, 0, AUX);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(I4, v), r, off, soff, AUX);
     }
 }
 template <class T>
-__device__ __forceinline__ void buf_store1(__amdgpu_buffer_rsrc_t r, unsigned off, T v) {
+__device__ __forceinline__ void buf_store1(__amdgpu_buffer_rsrc_t r, unsigned off, T v, unsigned soff = 0) {
     if constexpr (sizeof(T) == 4) {
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, off, soff, 0);
     } else {
         typedef int I2 __attribute__((ext_vector_type(2)));
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(I2, v), r, off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(I2, v), r, off, soff, 0);
     }
 }
 
 template <class T>
-__device__ __forceinline__ T buf_load1(__amdgpu_buffer_rsrc_t r, unsigned off) {  // out of range: returns 0
+__device__ __forceinline__ T buf_load1(__amdgpu_buffer_rsrc_t r, unsigned off, unsigned soff = 0) {  // out of range: 0
     if constexpr (sizeof(T) == 4) {
-        return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+        return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b32(r, off, soff, 0));
     } else {
         typedef int I2 __attribute__((ext_vector_type(2)));
-        return __builtin_bit_cast(T, (I2)__builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0));
+        return __builtin_bit_cast(T, (I2)__builtin_amdgcn_raw_buffer_load_b64(r, off, soff, 0));
     }
 }
 
@@ -1108,6 +1120,15 @@ struct SkShared {
 //      field before add_source; rhs = x0 + dt * x (the expression of add_source_kernel) replaces x0 for every level
 //      the moment its plane arrives and is stored to x0out for the later launches (interior cells of the chunk);
 //   3  project: the iterate is identically zero — no x is requested at all, level 1 is evaluated on literal zeros.
+// Where a lane of a j-wall workgroup meets the walls. Row t of a tile (t = wave x TJ + r) is j = jb x V + 1 - S + t:
+// j = 1 is row S of the first j-block and j = N row jtN of the last one — the same row for every such lane, so "is this
+// row at the wall" is a wave-uniform test of t combined with a lane mask, not a per-lane comparison per row.
+struct SkWall {
+    bool lo, hi;  // the lane belongs to the first / last j-block
+    bool hi2;     // ... to the one before the last: its upper halo rows can reach j = N (tile row jtN + V)
+    int jtN;      // tile row of j = N in the last j-block (rows beyond it do not exist)
+};
+
 template <class T, int TJ>
 struct SkFirst {
     T xs[4][TJ];         // ring of the row-end shell cells of x (modes 1, 2)
@@ -1118,41 +1139,73 @@ struct SkFirst {
 
 template <class T, int WL, bool NT, int S, int TJ, int NW, int PH, int NACT, bool WALLS, bool ISH, bool ROWEND, int FIRST>
 __device__ __forceinline__ void jsk_step(const Geom& g, SkShared<T, WL, S, TJ, NW>& sh,
-                                         typename LaneVec<T, WL>::type (&xr)[4][TJ],
-                                         typename LaneVec<T, WL>::type (&yr)[S - 1][4][TJ],
+                                         typename LaneVec<T, WL>::type (&xr)[S == 4 ? 3 : 4][TJ],
+                                         typename LaneVec<T, WL>::type (&yr)[S - 1][S == 4 ? 3 : 4][TJ],
                                          typename LaneVec<T, WL>::type (&sr)[S == 4 ? 5 : 4][TJ],
-                                         const unsigned (&rowb)[TJ], const unsigned (&rowst)[TJ],
-                                         const T* __restrict__& px,
+                                         unsigned row0, unsigned stcol, const T* __restrict__& px,
                                          const T* __restrict__& ps0, T* __restrict__& pout, int kk, T a, T inv, T sx,
-                                         T sy, T sz, int jrow0, int wave, int lane, bool first_vec, bool last_vec,
+                                         T sy, T sz, SkWall jw, int wave, int lane, bool first_vec, bool last_vec,
                                          SkFirst<T, TJ>& fx) {
     typedef typename LaneVec<T, WL>::type VW;
     static_assert(FIRST == 0 || S == 4, "first passes exist as four-sweep launches only");
     const int N = g.N;
     const int kmax = g.np - 1;
-    constexpr unsigned OOBL = 0xFFFFFF00u;
+    constexpr unsigned OOBL = SK_OOB;
     constexpr int RB = (PH + 1) & 1, WB = PH & 1;  // LDS buffer read (written one step ago) / written in this step
+    // Row addressing: row r of the lane's tile is (row0: the byte offset of its row 0) + r rows, the r rows through
+    // the instruction's scalar offset — one register for TJ rows. Row 0 of the first j-block lies S-1 rows below the
+    // plane, so every plane resource starts S-1 rows early (jsk_march shifts the field pointers) and row0 counts from there (a buffer offset cannot be
+    // negative); rows outside the plane read the padding or the neighbouring plane (SK_PAD_ROWS_*). A lane / row that
+    // must not be stored — feeder lanes: stcol is out of range; the outer S rows of the tile: wave-uniform; on a j
+    // wall also rows beyond N: per lane — carries the out-of-range offset instead.
+    const unsigned pxb = (unsigned)g.px * (unsigned)sizeof(T);
+    auto prs = [&](const T* pl) -> __amdgpu_buffer_rsrc_t { return plane_rsrc(pl); };  // (pointers arrive shifted)
+    auto rv = [&](int) -> unsigned { return row0; };
+    auto rs_ = [&](int r) -> unsigned { return (unsigned)r * pxb; };
+    auto row_stored = [&](int r) -> bool {  // wave-uniform
+        const int jt = wave * TJ + r;
+        return jt >= S && jt < NW * TJ - S;
+    };
+    // (these offsets are loop-invariant and hipcc holds one per row, shell cell and face through the march; hiding
+    // stcol from the optimizer once per step frees those registers, but measured 2 % slower at four rows per wave)
+    const unsigned stc = stcol;
+    auto st_off = [&](int r) -> unsigned {
+        if constexpr (!WALLS) return row_stored(r) ? stc : SK_OOB;
+        else return (row_stored(r) && !(jw.hi && wave * TJ + r > jw.jtN)) ? stc : SK_OOB;
+    };
+    // on a j wall: is row r of this lane j = 1 / j = N? (SkWall: a wave-uniform test of the row and a lane mask)
+    auto at_jlo = [&](int r) -> bool { return WALLS && jw.lo && wave * TJ + r == S; };
+    auto at_jhi = [&](int r) -> bool {
+        constexpr int V = NW * TJ - 2 * S;
+        return WALLS && ((jw.hi && wave * TJ + r == jw.jtN) || (jw.hi2 && wave * TJ + r == jw.jtN + V));
+    };
+    constexpr bool XSH = S == 4;  // x in a three-slot shift register (0 = plane kk-1, 1 = kk, 2 = kk+1), see below
     // (1) requests for the next step: x(kk+2), x0(kk+1). px / ps0 point at those planes and advance by one plane per
     // step (held at the last stored plane: the values requested beyond it are never used)
-    {
-        const __amdgpu_buffer_rsrc_t rd = plane_rsrc(px);
-        const __amdgpu_buffer_rsrc_t rs = plane_rsrc(ps0);
-        // (held at plane 0 while the index is still negative — a chunk that starts at the first plane reaches S-1
-        // planes below it — and at the last stored plane beyond it: values requested outside are never used)
-        px += (kk + 2 >= 0 && kk + 2 < kmax) ? g.plane : 0;
-        ps0 += (kk + 1 >= 0 && kk + 1 < kmax) ? g.plane : 0;
+    const __amdgpu_buffer_rsrc_t rd = prs(px);
+    // (held at plane 0 while the index is still negative — a chunk that starts at the first plane reaches S-1
+    // planes below it — and at the last stored plane beyond it: values requested outside are never used)
+    px += (kk + 2 >= 0 && kk + 2 < kmax) ? g.plane : 0;
+    auto request_x = [&]() {
+        constexpr int slot = XSH ? 2 : ((PH + 2) & 3);
         if constexpr (FIRST != 3) {
 #pragma unroll
-            for (int r = 0; r < TJ; ++r) xr[(PH + 2) & 3][r] = buf_load<T, WL>(rd, rowb[r]);
+            for (int r = 0; r < TJ; ++r) xr[slot][r] = buf_load<T, WL>(rd, rv(r), rs_(r));
         }
         if constexpr ((FIRST == 1 || FIRST == 2) && ROWEND) {
 #pragma unroll
             for (int r = 0; r < TJ; ++r) {
-                const unsigned off = first_vec ? rowb[r] - (unsigned)sizeof(T)
-                                               : (last_vec ? rowb[r] + WL * (unsigned)sizeof(T) : OOBL);
-                fx.xs[(PH + 2) & 3][r] = buf_load1<T>(rd, off);
+                const unsigned off = first_vec ? rv(r) - (unsigned)sizeof(T)
+                                               : (last_vec ? rv(r) + WL * (unsigned)sizeof(T) : OOBL);
+                fx.xs[(PH + 2) & 3][r] = buf_load1<T>(rd, off, rs_(r));
             }
         }
+    };
+    {
+        const __amdgpu_buffer_rsrc_t rs = prs(ps0);
+        ps0 += (kk + 1 >= 0 && kk + 1 < kmax) ? g.plane : 0;
+        // S = 4: the request for x is issued after level 1 (below), into the slot level 1 has just released
+        if constexpr (!XSH) request_x();
         if constexpr (S == 4) {
             // five planes of x0 are live with four levels (one in flight): not a divisor of the four-fold unrolled
             // march, so x0 is a shift register: slot l serves level l, slot 0 receives the request
@@ -1161,42 +1214,52 @@ __device__ __forceinline__ void jsk_step(const Geom& g, SkShared<T, WL, S, TJ, N
 #pragma unroll
                 for (int r = 0; r < TJ; ++r) sr[l][r] = sr[l - 1][r];
 #pragma unroll
-            for (int r = 0; r < TJ; ++r) sr[0][r] = buf_load<T, WL>(rs, rowb[r]);
+            for (int r = 0; r < TJ; ++r) sr[0][r] = buf_load<T, WL>(rs, rv(r), rs_(r));
         } else {
 #pragma unroll
-            for (int r = 0; r < TJ; ++r) sr[(PH + 1) & 3][r] = buf_load<T, WL>(rs, rowb[r]);
+            for (int r = 0; r < TJ; ++r) sr[(PH + 1) & 3][r] = buf_load<T, WL>(rs, rv(r), rs_(r));
         }
     }
+    // ring slots of x(kk-1), x(kk), x(kk+1)
+    constexpr int XM = XSH ? 0 : ((PH + 3) & 3), XC = XSH ? 1 : ((PH + 0) & 3), XP = XSH ? 2 : ((PH + 1) & 3);
     if constexpr (FIRST == 2) {
         // x0(kk) has arrived (slot 1 after the shift) and x(kk) = the source is the centre plane of level 1: form the
         // right-hand side of this plane once, for every level, and store it where the later launches read it
         const bool inr = kk >= fx.k0 && kk < fx.k1;  // wave-uniform: planes of this chunk
-        const __amdgpu_buffer_rsrc_t rr = plane_rsrc(fx.prhs);
+        const __amdgpu_buffer_rsrc_t rr = prs(fx.prhs);
         fx.prhs += (kk >= 0 && kk < kmax) ? g.plane : 0;
 #pragma unroll
         for (int r = 0; r < TJ; ++r) {
             VW rhs;
 #pragma unroll
-            for (int e = 0; e < WL; ++e) rhs[e] = sr[1][r][e] + fx.dt * xr[(PH + 0) & 3][r][e];
+            for (int e = 0; e < WL; ++e) rhs[e] = sr[1][r][e] + fx.dt * xr[XC][r][e];
             sr[1][r] = rhs;
-            buf_store<T, WL, false>(rr, inr ? rowst[r] : OOBL, rhs);
+            buf_store<T, WL, false>(rr, inr ? st_off(r) : OOBL, rhs, rs_(r));
         }
     }
     // (2) the neighbours' edge rows of every active source level (published in the previous step)
     const int wlo = wave > 0 ? wave - 1 : 0, whi = wave < NW - 1 ? wave + 1 : NW - 1;
+    // (read one level ahead of their use — level 1's here, level l+1's while level l computes — so that only two
+    // pairs are live at a time: with four levels all eight at once cost the registers that decide between four and
+    // five rows per wave)
     VW hm[S], hp[S];
-#pragma unroll
-    for (int l = 1; l <= NACT; ++l) {
+    auto read_halo = [&](int l) {
         if (FIRST == 3 && l == 1) {
 #pragma unroll
             for (int e = 0; e < WL; ++e) {
                 hm[0][e] = T(0);
                 hp[0][e] = T(0);
             }
-            continue;
+        } else {
+            hm[l - 1] = sh.edge[RB][l - 1][wlo][1][lane];
+            hp[l - 1] = sh.edge[RB][l - 1][whi][0][lane];
         }
-        hm[l - 1] = sh.edge[RB][l - 1][wlo][1][lane];
-        hp[l - 1] = sh.edge[RB][l - 1][whi][0][lane];
+    };
+    if constexpr (S == 4) {
+        read_halo(1);
+    } else {
+#pragma unroll
+        for (int l = 1; l <= NACT; ++l) read_halo(l);
     }
     __builtin_amdgcn_sched_barrier(0);
     // (3) levels 1 .. NACT
@@ -1208,7 +1271,23 @@ __device__ __forceinline__ void jsk_step(const Geom& g, SkShared<T, WL, S, TJ, N
         // k walls are handled in every instantiation: wave-uniform tests, true in at most S-1 steps per chunk end
         const bool klo = l >= 2 && g.wall_lo && kg == 1, khi = l >= 2 && g.wall_hi && kg == N;
         T* __restrict__ po = pout;  // plane kk-S+1: only used by level S
-        const __amdgpu_buffer_rsrc_t rc = plane_rsrc(po);
+        const __amdgpu_buffer_rsrc_t rc = prs(po);
+        if constexpr (S == 4) {
+            if (l + 1 <= NACT) read_halo(l + 1);
+        }
+        // S = 4: the intermediate levels live in three-slot shift registers (0 = the plane written in this step, 1, 2
+        // = the two before it) instead of four-slot rings — a v_mov is free in a request-bound kernel, the fifteen
+        // vectors it saves are what lets a wave hold five rows
+        constexpr bool YSH = S == 4;
+        if constexpr (YSH) {
+            if (l < S) {
+#pragma unroll
+                for (int r = 0; r < TJ; ++r) {
+                    yr[l - 1 < S - 1 ? l - 1 : 0][2][r] = yr[l - 1 < S - 1 ? l - 1 : 0][1][r];
+                    yr[l - 1 < S - 1 ? l - 1 : 0][1][r] = yr[l - 1 < S - 1 ? l - 1 : 0][0][r];
+                }
+            }
+        }
 #pragma unroll
         for (int r = 0; r < TJ; ++r) {
             VW cc, km, kp, jm, jp;
@@ -1216,20 +1295,22 @@ __device__ __forceinline__ void jsk_step(const Geom& g, SkShared<T, WL, S, TJ, N
 #pragma unroll
                 for (int e = 0; e < WL; ++e) cc[e] = km[e] = kp[e] = jm[e] = jp[e] = T(0);
             } else if (l == 1) {
-                cc = xr[(PH + 0) & 3][r];
-                km = xr[(PH + 3) & 3][r];
-                kp = xr[(PH + 1) & 3][r];
-                jm = r > 0 ? xr[(PH + 0) & 3][r > 0 ? r - 1 : 0] : hm[0];
-                jp = r < TJ - 1 ? xr[(PH + 0) & 3][r < TJ - 1 ? r + 1 : 0] : hp[0];
+                cc = xr[XC][r];
+                km = xr[XM][r];
+                kp = xr[XP][r];
+                jm = r > 0 ? xr[XC][r > 0 ? r - 1 : 0] : hm[0];
+                jp = r < TJ - 1 ? xr[XC][r < TJ - 1 ? r + 1 : 0] : hp[0];
             } else {
                 const int q = l >= 2 ? l - 2 : 0;
-                cc = yr[q][(PH + 5 - l) & 3][r];
-                km = yr[q][(PH + 4 - l) & 3][r];
-                kp = yr[q][(PH + 6 - l) & 3][r];
-                jm = r > 0 ? yr[q][(PH + 5 - l) & 3][r > 0 ? r - 1 : 0] : hm[l - 1];
-                jp = r < TJ - 1 ? yr[q][(PH + 5 - l) & 3][r < TJ - 1 ? r + 1 : 0] : hp[l - 1];
+                constexpr int NS = S == 4 ? 3 : 4;
+                const int sc = YSH ? 1 : ((PH + 5 - l) & 3), sm = YSH ? 2 : ((PH + 4 - l) & 3),
+                          sp = YSH ? 0 : ((PH + 6 - l) & 3);
+                cc = yr[q][sc % NS][r];
+                km = yr[q][sm % NS][r];
+                kp = yr[q][sp % NS][r];
+                jm = r > 0 ? yr[q][sc % NS][r > 0 ? r - 1 : 0] : hm[l - 1];
+                jp = r < TJ - 1 ? yr[q][sc % NS][r < TJ - 1 ? r + 1 : 0] : hp[l - 1];
             }
-            const int j = jrow0 + r;
             // (left + right): the i-neighbours of the lane's end cells live in the adjacent lanes; at a row end they
             // are the i-shell cells sx * (end cell) instead (ROWEND: does this workgroup hold a row end at all?)
             VW lr;
@@ -1263,8 +1344,9 @@ __device__ __forceinline__ void jsk_step(const Geom& g, SkShared<T, WL, S, TJ, N
             }
             if (l >= 2) {  // set_bnd of the source level on the j / k walls
                 if (WALLS) {
-                    if (j == 1) jm = sy * cc;
-                    if (j == N) jp = sy * cc;
+                    // (as selects: a wave-uniform branch per row around them measured 7 % slower at 256^3)
+                    if (at_jlo(r)) jm = sy * cc;
+                    if (at_jhi(r)) jp = sy * cc;
                 }
                 if (klo) km = sz * cc;
                 if (khi) kp = sz * cc;
@@ -1274,17 +1356,17 @@ __device__ __forceinline__ void jsk_step(const Geom& g, SkShared<T, WL, S, TJ, N
 #pragma unroll
             for (int e = 0; e < WL; ++e) o[e] = (s[e] + a * ((lr[e] + (jm[e] + jp[e])) + (km[e] + kp[e]))) * inv;
             if (l < S) {
-                yr[l - 1 < S - 1 ? l - 1 : 0][(PH + 5 - l) & 3][r] = o;
+                yr[l - 1 < S - 1 ? l - 1 : 0][YSH ? 0 : ((PH + 5 - l) & 3) % (S == 4 ? 3 : 4)][r] = o;
             } else {
-                // rowst[r]: the row's store offset, or an out-of-range one if this lane / row must not store (feeder
+                // st_off(r): the row's store offset, or an out-of-range one if this lane / row must not store (feeder
                 // lane, outer S rows of the workgroup's tile, row beyond N)
-                constexpr unsigned OOB = 0xFFFFFF00u;
-                const bool valid = rowst[r] != OOB;
+                constexpr unsigned OOB = SK_OOB;
                 // No branch around the stores (a "stored / not stored" join makes hipcc wait for every older store at
                 // the next s_waitcnt): lanes that must not store carry an offset beyond the resource's range, and the
                 // hardware drops an out-of-range buffer store.
-                if constexpr (!WALLS) {
-                    const unsigned offv = rowst[r];
+                {
+                    const unsigned offv = st_off(r);
+                    const unsigned so = rs_(r);
                     // the i = 0 / N+1 shell cell of a row end: ONE store instruction per row serves whichever end the
                     // lane sits at (a lane is never both: rows hold >= 2 vectors), and only workgroups that hold a
                     // row end issue it at all. (The last pass of a solve still costs 25-35 % more than a plain one at
@@ -1292,11 +1374,12 @@ __device__ __forceinline__ void jsk_step(const Geom& g, SkShared<T, WL, S, TJ, N
                     // before the row, cell N+1 starts the one after it when N % 32 == 0 — are partial writes to HBM.
                     // Non-temporal, whole-32-byte-sector and all-lanes-in-range forms of this store measured the same.)
                     constexpr bool SHELL = ISH && ROWEND;
-                    const unsigned offsh = (SHELL && valid && first_vec) ? rowb[r] - (unsigned)sizeof(T)
-                                           : ((SHELL && valid && last_vec) ? rowb[r] + WL * (unsigned)sizeof(T) : OOB);
+                    // (offv is the row's offset or out of range: the shell cell sits one cell before / WL cells after it)
+                    const unsigned offsh = (SHELL && offv != OOB && first_vec) ? offv - (unsigned)sizeof(T)
+                                           : ((SHELL && offv != OOB && last_vec) ? offv + WL * (unsigned)sizeof(T) : OOB);
                     const T osh = first_vec ? o[0] : o[WL - 1];
-                    buf_store<T, WL, NT>(rc, offv, o);
-                    if constexpr (SHELL) buf_store1<T>(rc, offsh, sx * osh);
+                    buf_store<T, WL, NT>(rc, offv, o, so);
+                    if constexpr (SHELL) buf_store1<T>(rc, offsh, sx * osh, so);
                     // first / last plane of a wall slab (wave-uniform, one step per chunk end): the k face of this row
                     // and, with the i-shell, its two i-k edge cells — the expressions of emit_shells
                     const bool kslo = g.wall_lo && kg == 1, kshi = g.wall_hi && kg == N;
@@ -1307,39 +1390,79 @@ __device__ __forceinline__ void jsk_step(const Geom& g, SkShared<T, WL, S, TJ, N
                         for (int e = 0; e < WL; ++e) t[e] = sz * o[e];
                         const T esh = half * (sz * osh + sx * osh);  // the i-k edge cell of that row end
                         if (kslo) {
-                            const __amdgpu_buffer_rsrc_t rk = plane_rsrc(po - g.plane);
-                            buf_store<T, WL, false>(rk, offv, t);
-                            if constexpr (SHELL) buf_store1<T>(rk, offsh, esh);
+                            const __amdgpu_buffer_rsrc_t rk = prs(po - g.plane);
+                            buf_store<T, WL, false>(rk, offv, t, so);
+                            if constexpr (SHELL) buf_store1<T>(rk, offsh, esh, so);
                         }
                         if (kshi) {
-                            const __amdgpu_buffer_rsrc_t rk = plane_rsrc(po + g.plane);
-                            buf_store<T, WL, false>(rk, offv, t);
-                            if constexpr (SHELL) buf_store1<T>(rk, offsh, esh);
+                            const __amdgpu_buffer_rsrc_t rk = prs(po + g.plane);
+                            buf_store<T, WL, false>(rk, offv, t, so);
+                            if constexpr (SHELL) buf_store1<T>(rk, offsh, esh, so);
                         }
                     }
-                } else if (valid) {
-                    buf_store<T, WL, NT>(rc, rowb[r], o);
-                    const bool kslo = g.wall_lo && kg == 1, kshi = g.wall_hi && kg == N;
-                    if ((j == 1) | (j == N) | kslo | kshi | (ISH && (first_vec | last_vec))) {
-                        const unsigned pxb = (unsigned)g.px * (unsigned)sizeof(T);
-                        j2k_shells<T, WL>(plane_rsrc(po - g.plane), rc, plane_rsrc(po + g.plane), rowb[r], rowb[r] - pxb,
-                                          rowb[r] + pxb, o, sx, sy, sz, j == 1, j == N, kslo, kshi, ISH && first_vec,
-                                          ISH && last_vec);
+                    if constexpr (WALLS) {
+                        // a row next to a j wall (per lane; no lane in most waves and steps, so the branch is skipped):
+                        // the j face cell of every interior cell of the row, the i-j edge cells at a row end, and on a
+                        // first / last plane the j-k edge cells and the corners — the expressions of emit_shells
+                        const bool jlo = at_jlo(r), jhi = at_jhi(r);
+                        if ((jlo | jhi) && offv != OOB) {
+                            const T half = T(0.5);
+                            // (row r-1 / r+1 of the tile: the row below is reached through the scalar offset — offv
+                            // alone can be row 0 of the resource, and a buffer offset must not go below zero)
+                            const unsigned sj = r > 0 ? so - pxb : so;
+                            const unsigned offj = r > 0 ? (jlo ? offv : offv + 2 * pxb) : (jlo ? offv - pxb : offv + pxb);
+                            const unsigned offjs = first_vec ? offj - (unsigned)sizeof(T)
+                                                             : (last_vec ? offj + WL * (unsigned)sizeof(T) : OOB);
+                            VW t;
+#pragma unroll
+                            for (int e = 0; e < WL; ++e) t[e] = sy * o[e];
+                            buf_store<T, WL, false>(rc, offj, t, sj);
+                            if constexpr (SHELL) buf_store1<T>(rc, offjs, half * (sy * osh + sx * osh), sj);
+                            if (kslo | kshi) {
+                                const __amdgpu_buffer_rsrc_t rk = prs(kslo ? po - g.plane : po + g.plane);
+#pragma unroll
+                                for (int e = 0; e < WL; ++e) t[e] = half * (sz * o[e] + sy * o[e]);
+                                buf_store<T, WL, false>(rk, offj, t, sj);
+                                if constexpr (SHELL) {
+                                    const T third = (T)(1.0 / 3.0);
+                                    const T ex = half * (sz * osh + sy * osh);
+                                    const T ey = half * (sz * osh + sx * osh);
+                                    const T ez = half * (sy * osh + sx * osh);
+                                    buf_store1<T>(rk, offjs, third * ((ex + ey) + ez), sj);
+                                }
+                            }
+                        }
                     }
                 }
+            }
+        }
+        if constexpr (XSH) {
+            if (l == 1) {
+                // level 1 was the last reader of x(kk-1): shift, and request x(kk+2) into the slot that fell free
+                // (three planes of x live instead of four; the request still has levels 2..S and the start of the
+                // next step to arrive in)
+#pragma unroll
+                for (int r = 0; r < TJ; ++r) {
+                    xr[0][r] = xr[1][r];
+                    xr[1][r] = xr[2][r];
+                }
+                request_x();
             }
         }
     }
     // (4) publish this wave's edge rows: x(kk+1) and every intermediate level computed in this step
     if constexpr (FIRST != 3) {
-        sh.edge[WB][0][wave][0][lane] = xr[(PH + 1) & 3][0];
-        sh.edge[WB][0][wave][1][lane] = xr[(PH + 1) & 3][TJ - 1];
+        constexpr int XN = XSH ? 1 : ((PH + 1) & 3);  // x(kk+1): after the shift it is the centre slot
+        sh.edge[WB][0][wave][0][lane] = xr[XN][0];
+        sh.edge[WB][0][wave][1][lane] = xr[XN][TJ - 1];
     }
 #pragma unroll
     for (int l = 1; l < S; ++l)
         if (l <= NACT) {
-            sh.edge[WB][l][wave][0][lane] = yr[l - 1][(PH + 5 - l) & 3][0];
-            sh.edge[WB][l][wave][1][lane] = yr[l - 1][(PH + 5 - l) & 3][TJ - 1];
+            constexpr int NS = S == 4 ? 3 : 4;
+            const int sw = (S == 4) ? 0 : (((PH + 5 - l) & 3) % NS);
+            sh.edge[WB][l][wave][0][lane] = yr[l - 1][sw][0];
+            sh.edge[WB][l][wave][1][lane] = yr[l - 1][sw][TJ - 1];
         }
     if (NACT == S) pout += g.plane;
     // (5) one barrier per step (LDS only: the global requests stay in flight across it)
@@ -1347,19 +1470,29 @@ __device__ __forceinline__ void jsk_step(const Geom& g, SkShared<T, WL, S, TJ, N
 }
 
 template <class T, int WL, bool NT, int S, int TJ, int NW, bool WALLS, bool ISH, bool ROWEND, int FIRST>
-__device__ __forceinline__ void jsk_march(const Geom& g, SkShared<T, WL, S, TJ, NW>& sh, const unsigned (&rowb)[TJ],
-                                          const unsigned (&rowst)[TJ], const T* __restrict__ x,
+__device__ __forceinline__ void jsk_march(const Geom& g, SkShared<T, WL, S, TJ, NW>& sh, unsigned row0, unsigned stcol,
+                                          const T* __restrict__ x,
                                           const T* __restrict__ x0, T* __restrict__ xn, int k0, int k1, T a, T inv, T sx,
-                                          T sy, T sz, int jrow0, int wave, int lane, bool first_vec, bool last_vec,
+                                          T sy, T sz, SkWall jw, int wave, int lane, bool first_vec, bool last_vec,
                                           T* __restrict__ x0out, T dt) {
     typedef typename LaneVec<T, WL>::type VW;
     static_assert(S >= 2 && S <= 4, "two, three or four fused sweeps");
+    // every plane resource starts S-1 rows before its plane (jsk_step): shift the field pointers once
+    x -= (long)(S - 1) * g.px;
+    x0 -= (long)(S - 1) * g.px;
+    xn -= (long)(S - 1) * g.px;
+    x0out -= (long)(S - 1) * g.px;
     const int kmax = g.np - 1;
     auto plane_of_k = [&](const T* base, int kl) -> __amdgpu_buffer_rsrc_t {
         kl = kl < 0 ? 0 : (kl > kmax ? kmax : kl);
         return plane_rsrc(base + (long)kl * g.plane);
     };
-    VW xr[4][TJ], yr[S - 1][4][TJ], sr[S == 4 ? 5 : 4][TJ];
+    constexpr bool XSH = S == 4;
+    constexpr int XA = XSH ? 0 : 3, XB = XSH ? 1 : 0, XC = XSH ? 2 : 1;  // slots of x(kk-1), x(kk), x(kk+1)
+    const unsigned pxb = (unsigned)g.px * (unsigned)sizeof(T);
+    auto rv = [&](int) -> unsigned { return row0; };
+    auto rs_ = [&](int r) -> unsigned { return (unsigned)r * pxb; };
+    VW xr[XSH ? 3 : 4][TJ], yr[S - 1][S == 4 ? 3 : 4][TJ], sr[S == 4 ? 5 : 4][TJ];
     int kk = k0 - S + 1;  // first step; ring phase 0
     SkFirst<T, TJ> fx;
     fx.dt = dt;
@@ -1373,30 +1506,30 @@ __device__ __forceinline__ void jsk_march(const Geom& g, SkShared<T, WL, S, TJ, 
 #pragma unroll
         for (int r = 0; r < TJ; ++r) {
             if constexpr (FIRST != 3) {
-                xr[3][r] = buf_load<T, WL>(pa, rowb[r]);
-                xr[0][r] = buf_load<T, WL>(pb, rowb[r]);
-                xr[1][r] = buf_load<T, WL>(pc, rowb[r]);
+                xr[XA][r] = buf_load<T, WL>(pa, rv(r), rs_(r));
+                xr[XB][r] = buf_load<T, WL>(pb, rv(r), rs_(r));
+                xr[XC][r] = buf_load<T, WL>(pc, rv(r), rs_(r));
             } else {
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
+                for (int q = 0; q < (XSH ? 3 : 4); ++q)
 #pragma unroll
                     for (int e = 0; e < WL; ++e) xr[q][r][e] = T(0);
             }
-            sr[0][r] = buf_load<T, WL>(ps, rowb[r]);
+            sr[0][r] = buf_load<T, WL>(ps, rv(r), rs_(r));
         }
         if constexpr ((FIRST == 1 || FIRST == 2) && ROWEND) {
 #pragma unroll
             for (int r = 0; r < TJ; ++r) {
-                const unsigned off = first_vec ? rowb[r] - (unsigned)sizeof(T)
-                                               : (last_vec ? rowb[r] + WL * (unsigned)sizeof(T) : 0xFFFFFF00u);
-                fx.xs[0][r] = buf_load1<T>(pb, off);
-                fx.xs[1][r] = buf_load1<T>(pc, off);
+                const unsigned off = first_vec ? rv(r) - (unsigned)sizeof(T)
+                                               : (last_vec ? rv(r) + WL * (unsigned)sizeof(T) : SK_OOB);
+                fx.xs[0][r] = buf_load1<T>(pb, off, rs_(r));
+                fx.xs[1][r] = buf_load1<T>(pc, off, rs_(r));
             }
         }
         // the first step reads the edges of x(kk) from buffer 1
         if constexpr (FIRST != 3) {
-            sh.edge[1][0][wave][0][lane] = xr[0][0];
-            sh.edge[1][0][wave][1][lane] = xr[0][TJ - 1];
+            sh.edge[1][0][wave][0][lane] = xr[XB][0];
+            sh.edge[1][0][wave][1][lane] = xr[XB][TJ - 1];
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
@@ -1405,9 +1538,9 @@ __device__ __forceinline__ void jsk_march(const Geom& g, SkShared<T, WL, S, TJ, 
     const T* __restrict__ ps0 = x0 + (long)(kk + 1 > kmax ? kmax : (kk + 1 < 0 ? 0 : kk + 1)) * g.plane;
     T* __restrict__ pout = xn + (long)k0 * g.plane;
 #define SF_SK_STEP(PH_, NACT_)                                                                                       \
-    jsk_step<T, WL, NT, S, TJ, NW, PH_, NACT_, WALLS, ISH, ROWEND, FIRST>(g, sh, xr, yr, sr, rowb, rowst, px, ps0, pout, \
-                                                                          kk, a, inv, sx, sy, sz, jrow0, wave, lane,    \
-                                                                          first_vec, last_vec, fx)
+    jsk_step<T, WL, NT, S, TJ, NW, PH_, NACT_, WALLS, ISH, ROWEND, FIRST>(g, sh, xr, yr, sr, row0, stcol, px, \
+                                                                          ps0, pout, kk, a, inv, sx, sy, sz, jw,       \
+                                                                          wave, lane, first_vec, last_vec, fx)
     const int kend = k1 + S - 2;  // last step
     SF_SK_STEP(0, 1);
     ++kk;
@@ -1478,7 +1611,6 @@ __global__ void __launch_bounds__(64 * NW, SF_SK_WAVES) jacobi_sk_kernel(Geom g,
     __shared__ SkShared<T, WL, S, TJ, NW> sh;
     const int N = g.N;
     const int nvec = N / WL;
-    const int cb = (int)blockIdx.x * m.band + (int)blockIdx.y;  // column block; workgroup x runs on XCD group x
     int chunk, f;
     {
         const int nchunk = (ke - kb + m.kc - 1) / m.kc;
@@ -1490,10 +1622,17 @@ __global__ void __launch_bounds__(64 * NW, SF_SK_WAVES) jacobi_sk_kernel(Geom g,
             f = (int)blockIdx.z / nchunk;
         }
     }
+    // Column block: workgroup x of the grid runs on XCD x, and the column blocks of one band (neighbours in j and i, who
+    // read each other's halo rows) share an XCD's L2. The bands rarely divide evenly — 18 column blocks in bands of 3
+    // leave two XCDs without work — so the band -> XCD assignment rotates with the chunk: over the chunks of a launch
+    // every XCD receives the same number of workgroups.
+    // A launch whose workgroups all fit the chip at once (band == 0) is as slow as its fullest XCD: there the column
+    // blocks are dealt out one by one (the hardware sends consecutive workgroups to consecutive XCDs).
+    const int cb = m.band > 0 ? (int)((blockIdx.x + (unsigned)chunk) & 7u) * m.band + (int)blockIdx.y : (int)blockIdx.x;
     if (cb >= m.ncb) return;  // whole workgroups
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int total = m.njb * nvec;
     int t = cb * P + lane - F;
     const bool active = t >= 0 && t < total && lane >= F && lane < 64 - F;
@@ -1501,7 +1640,12 @@ __global__ void __launch_bounds__(64 * NW, SF_SK_WAVES) jacobi_sk_kernel(Geom g,
     const int jb = nvec == 1 ? t : (int)__umulhi((unsigned)t, m.nvec_magic);
     const int vec = t - jb * nvec;
     const int i0 = 1 + WL * vec;
-    const int jrow0 = jb * V + 1 - S + wave * TJ;  // j of this lane's row 0 (may lie outside [0, N+1]: clamped below)
+    const int jrow0 = jb * V + 1 - S + wave * TJ;  // j of this lane's row 0 (may lie outside [0, N+1])
+    SkWall jw;
+    jw.lo = jb == 0;
+    jw.hi = jb == m.njb - 1;
+    jw.hi2 = jb == m.njb - 2;
+    jw.jtN = N - 1 + S - (m.njb - 1) * V;
     const int shift = chunk > 0 ? m.gap : 0;  // (gap != 0 only for the two-chunk boundary launch)
     const int k0 = kb + chunk * m.kc + shift;
     const int k1 = ((kb + chunk * m.kc + m.kc < ke) ? kb + chunk * m.kc + m.kc : ke) + shift;
@@ -1524,42 +1668,30 @@ __global__ void __launch_bounds__(64 * NW, SF_SK_WAVES) jacobi_sk_kernel(Geom g,
     const T sy = (b == 2) ? T(-1) : T(1);
     const T sz = (b == 3) ? T(-1) : T(1);
 
-    unsigned rowb[TJ];
-#pragma unroll
-    for (int r = 0; r < TJ; ++r) {
-        int j = jrow0 + r;
-        j = j < 0 ? 0 : (j > N + 1 ? N + 1 : j);
-        rowb[r] = (unsigned)(j * g.px + (g.lead - 1) + i0) * (unsigned)sizeof(T);
-    }
-    unsigned rowst[TJ];
-#pragma unroll
-    for (int r = 0; r < TJ; ++r) {
-        const int jt = wave * TJ + r;  // row inside the workgroup's tile: the outer S rows are not valid
-        rowst[r] = (active && jt >= S && jt < NW * TJ - S && jrow0 + r <= N) ? rowb[r] : 0xFFFFFF00u;
-    }
+    // byte offset of the lane's row 0 from the start of the plane resources, S-1 rows below the plane (jsk_step)
+    const unsigned row0 = (unsigned)((jrow0 + S - 1) * g.px + (g.lead - 1) + i0) * (unsigned)sizeof(T);
+    const unsigned stcol = active ? row0 : SK_OOB;
     const bool first_vec = (vec == 0), last_vec = (vec == nvec - 1);
-    // Does this WORKGROUP touch a j wall? (uniform over the workgroup, from its item range: every wave takes the same
-    // instantiation.) j walls live in the first / last j-block. k walls are cheap wave-uniform tests in every step.
-    int tlo = cb * P, thi = cb * P + P - 1;
-    thi = thi >= total ? total - 1 : thi;
-    const int jb_lo = nvec == 1 ? tlo : (int)__umulhi((unsigned)tlo, m.nvec_magic);
-    const int jb_hi = nvec == 1 ? thi : (int)__umulhi((unsigned)thi, m.nvec_magic);
-    const bool jwall = jb_lo == 0 || (jb_hi + 1) * V + S >= N;  // a tile row (halo included) is j = 1 or j = N
-    // ... and a row end (a lane, feeder lanes included, whose vector is the first or last of its row)? Uniform as well.
+    // Does this WORKGROUP touch a j wall? (uniform over the workgroup, from its item range, feeder lanes included —
+    // they run on the addresses of their own item, and off the walls rows are addressed without clamping: every wave
+    // takes the same instantiation.) j walls live in the first / last j-block. k walls are cheap wave-uniform tests in
+    // every step.
     int flo = cb * P - F, fhi = cb * P + P - 1 + F;
     flo = flo < 0 ? 0 : flo;
     fhi = fhi >= total ? total - 1 : fhi;
     const int fb_lo = nvec == 1 ? flo : (int)__umulhi((unsigned)flo, m.nvec_magic);
     const int fb_hi = nvec == 1 ? fhi : (int)__umulhi((unsigned)fhi, m.nvec_magic);
+    const bool jwall = fb_lo == 0 || (fb_hi + 1) * V + S >= N;  // a tile row (halo included) is j <= 1 or j >= N
+    // ... and a row end (a lane, feeder lanes included, whose vector is the first or last of its row)? Uniform as well.
     const bool rowend = fb_lo != fb_hi || flo - fb_lo * nvec == 0 || fhi - fb_hi * nvec == nvec - 1;
     if (jwall)
-        jsk_march<T, WL, NT, S, TJ, NW, true, ISH, true, FIRST>(g, sh, rowb, rowst, x, x0, xn, k0, k1, a, inv, sx, sy, sz, jrow0,
+        jsk_march<T, WL, NT, S, TJ, NW, true, ISH, true, FIRST>(g, sh, row0, stcol, x, x0, xn, k0, k1, a, inv, sx, sy, sz, jw,
                                                          wave, lane, first_vec, last_vec, x0out, A.dt);
     else if (rowend)
-        jsk_march<T, WL, NT, S, TJ, NW, false, ISH, true, FIRST>(g, sh, rowb, rowst, x, x0, xn, k0, k1, a, inv, sx, sy, sz, jrow0,
+        jsk_march<T, WL, NT, S, TJ, NW, false, ISH, true, FIRST>(g, sh, row0, stcol, x, x0, xn, k0, k1, a, inv, sx, sy, sz, jw,
                                                           wave, lane, first_vec, last_vec, x0out, A.dt);
     else
-        jsk_march<T, WL, NT, S, TJ, NW, false, ISH, false, FIRST>(g, sh, rowb, rowst, x, x0, xn, k0, k1, a, inv, sx, sy, sz, jrow0,
+        jsk_march<T, WL, NT, S, TJ, NW, false, ISH, false, FIRST>(g, sh, row0, stcol, x, x0, xn, k0, k1, a, inv, sx, sy, sz, jw,
                                                            wave, lane, first_vec, last_vec, x0out, A.dt);
 }
 
@@ -1869,6 +2001,90 @@ __global__ void __launch_bounds__(256) advect_kernel(Geom g, AdvectArgs<T, NF> A
         store_cells<T, W>(A.d[f], q - i0, i0, out[f], nv);
         emit_shells<T, W>(A.d[f], g, A.b[f], i0, j, kl, out[f], nv);
     }
+}
+
+// advect, one cell per lane ("wavefront shuffles for the trilinear lookups"): a wave holds 64 consecutive cells of a
+// row. The eight samples of a cell are four (j, k) corners x the pair (i0, i0+1); with one cell per lane the i0 sample
+// of lane l+1 IS the i0+1 sample of lane l whenever the two back-traces land in consecutive cells of the same row
+// (a smooth flow: almost always), so each lane requests its four i0 samples — 64 lanes x 4 bytes, consecutive up to
+// the few places where the integer part of a back-trace steps: whole lines instead of 8-byte pairs scattered at a
+// 16-byte stride — and takes the i0+1 samples from its neighbour lane by a DPP wave shift. Lanes whose neighbour
+// landed elsewhere, and lane 63, load their own i0+1 samples under an exec mask. (Waves of 63 cells whose lane 63 only
+// feeds, so that the masked loads are skipped in most waves, measured slower: 204 vs 176 us — rows no longer start on
+// a line.) Same values, same expressions as advect_kernel: bit-identical.
+template <class T, int NF>
+__global__ void __launch_bounds__(256) advect_row_kernel(Geom g, AdvectArgs<T, NF> A, int kb, int ke, int wpr) {
+    const int lane = (int)threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)blockIdx.x * 4 + ((int)threadIdx.x >> 6));
+    const int N = g.N;
+    const int row = wv / wpr;  // (wave-uniform: scalar arithmetic)
+    if (row >= N * (ke - kb)) return;
+    const int seg = wv - row * wpr;
+    const int kq = row / N;
+    const int kl = kb + kq, j = 1 + row - kq * N;
+    const int i = 1 + seg * 64 + lane;
+    const bool ok = i <= N;
+    const int ic = ok ? i : N;  // lanes past the row end repeat its last cell and store nothing
+    const T Nf = (T)N;
+    const T lo = T(0.5), hi = Nf + T(0.5);
+    const long q = row0(g, j, kl) + ic;
+    const T uu = A.u[q], vv = A.v[q], ww = A.w[q];
+    const int kg = g.kg0 + kl;
+    T x = (T)ic - A.dt0 * uu;
+    T y = (T)j - A.dt0 * vv;
+    T z = (T)kg - A.dt0 * ww;
+    if (x < lo) x = lo;
+    if (x > hi) x = hi;
+    if (y < lo) y = lo;
+    if (y > hi) y = hi;
+    if (z < lo) z = lo;
+    if (z > hi) z = hi;
+    int ia = (x == x) ? (int)x : 0;
+    int ja = (y == y) ? (int)y : 0;
+    int ka = (z == z) ? (int)z : 0;
+    ia = ia < 0 ? 0 : (ia > N ? N : ia);
+    ja = ja < 0 ? 0 : (ja > N ? N : ja);
+    ka = ka < 0 ? 0 : (ka > N ? N : ka);
+    const T s1 = x - (T)ia, t1 = y - (T)ja, r1 = z - (T)ka;
+    int kla = ka - g.kg0;  // local plane of k0; k1 = kla + 1 must also be stored
+    bool bad = false;
+    if (kla < 0 || kla > g.np - 2) {
+        bad = ok;
+        kla = kla < 0 ? 0 : g.np - 2;
+    }
+    const long p00 = row0(g, ja, kla) + ia;  // (i0,j0,k0); +plane: k1; +px: j1
+    // does the next lane's back-trace land in the next cell of the same row? (lane 63 receives 0: never equal)
+    const long pn = __builtin_bit_cast(long, lane_dn(__builtin_bit_cast(double, p00)));
+    const bool shared = pn == p00 + 1;
+    const long off[4] = {0, g.plane, g.px, g.px + g.plane};
+    T c0[NF][4], c1[NF][4] = {};
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) c0[f][c] = A.d0[f][p00 + off[c]];
+    if (!shared) {
+#pragma unroll
+        for (int f = 0; f < NF; ++f)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) c1[f][c] = A.d0[f][p00 + off[c] + 1];
+    }
+    const T s0 = T(1) - s1, t0 = T(1) - t1, r0 = T(1) - r1;
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const T nb = lane_dn(c0[f][c]);
+            c1[f][c] = shared ? nb : c1[f][c];
+        }
+        T out[1];
+        out[0] = s0 * (t0 * (r0 * c0[f][0] + r1 * c0[f][1]) + t1 * (r0 * c0[f][2] + r1 * c0[f][3])) +
+                 s1 * (t0 * (r0 * c1[f][0] + r1 * c1[f][1]) + t1 * (r0 * c1[f][2] + r1 * c1[f][3]));
+        if (ok) {
+            A.d[f][q] = out[0];
+            emit_shells<T, 1>(A.d[f], g, A.b[f], i, j, kl, out, 1);
+        }
+    }
+    if (bad) atomicOr(A.flag, 1);
 }
 
 // LDS-staged advect (opt-in, SF_ADVECT_LDS=1; a measured NEGATIVE result kept for the record: 1.5x slower than

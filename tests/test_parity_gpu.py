@@ -158,10 +158,20 @@ def test_lin_solve_zero_iters_is_noop(dtype):
         assert_same(fs.download("dens"), f["dens"], "K=0")
 
 
+@pytest.fixture(params=["default", "gather", "row"])
+def advect_form(request, monkeypatch):
+    """advect has two forms: per-cell gathers of (i0, i0+1) pairs, and one cell per lane with the i0+1 samples taken
+    from the neighbour lane (by default only for the three velocity components in fp32). SF_ADVECT_ROW = 0 / 2 force
+    one or the other for every call, so both forms see every size, dtype and boundary mode of these tests."""
+    if request.param != "default":
+        monkeypatch.setenv("SF_ADVECT_ROW", "0" if request.param == "gather" else "2")
+    return request.param
+
+
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "f64"])
 @pytest.mark.parametrize("b", [0, 1, 2, 3])
-@pytest.mark.parametrize("N", [1, 2, 5, 8, 16, 31, 34])
-def test_advect(N, b, dtype):
+@pytest.mark.parametrize("N", [1, 2, 5, 8, 16, 31, 34, 70, 130])
+def test_advect(N, b, dtype, advect_form):
     # velocities large enough to hit the clamp at both ends and every fractional position
     f = rand_fields(N, dtype, 6, scale=1.0)
     with make(N, dtype) as fs:
@@ -172,6 +182,28 @@ def test_advect(N, b, dtype):
     want = f["dens"].copy()
     O.advect(b, want, f["dens0"], f["u"], f["v"], f["w"], dtype(DT))
     assert_same(got, want, f"advect b={b}")
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "f64"])
+@pytest.mark.parametrize("N,b", [(34, 0), (70, 1), (130, 2), (200, 3)])
+def test_advect_smooth_flow(N, b, dtype, advect_form):
+    """A smooth velocity field (back-traces of up to ~2.5 cells that vary slowly along a row): neighbouring cells land
+    in neighbouring cells, the case in which the one-cell-per-lane form takes its i0+1 samples from the next lane —
+    with the integer part stepping a few times per row, where it must fall back to its own loads."""
+    f = rand_fields(N, dtype, 7, scale=1.0)
+    k, j, i = np.meshgrid(*(np.arange(N + 2, dtype=np.float64),) * 3, indexing="ij")
+    amp = 2.5 / (DT * N)
+    f["u"] = (amp * np.sin(2 * np.pi * i / N + 0.3) * np.cos(2 * np.pi * j / N)).astype(dtype)
+    f["v"] = (amp * np.cos(2 * np.pi * (i + k) / N)).astype(dtype)
+    f["w"] = (amp * np.sin(2 * np.pi * (j - i) / N + 1.1)).astype(dtype)
+    with make(N, dtype) as fs:
+        for n in ("dens", "dens0", "u", "v", "w"):
+            fs.upload(n, f[n])
+        fs.advect(b, "dens", "dens0", "u", "v", "w")
+        got = fs.download("dens")
+    want = f["dens"].copy()
+    O.advect(b, want, f["dens0"], f["u"], f["v"], f["w"], dtype(DT))
+    assert_same(got, want, f"advect (smooth flow) N={N} b={b}")
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "f64"])

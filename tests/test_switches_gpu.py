@@ -10,11 +10,13 @@ from test_parity_gpu import DT, DIFF, VISC, NAMES, assert_same, make, rand_field
 pytestmark = pytest.mark.gpu
 
 SWITCHES = [
-    {},                             # defaults (three-sweep marching kernel on one slab, two-sweep on slab interiors)
+    {},                             # defaults (four-sweep marching kernel, four ghost planes on slabs)
     {"SF_MARCH": "0"},              # register-blocked pair kernel everywhere
     {"SF_SK_S": "2"}, {"SF_SK_S": "3"},  # marching kernel limited to two / three sweeps per pass
     {"SF_SK_FIRST": "0"},           # first pass of a solve through the register-blocked pair kernel
+    {"SF_SK_LINEAR": "1"},          # single-round marching launches deal column blocks to the XCDs one by one
     {"SF_FUSE2": "0"},              # single sweeps, one ghost plane
+    {"SF_ADVECT_ROW": "0"}, {"SF_ADVECT_ROW": "2"},  # advect: gather form / one cell per lane, for every call
     {"SF_OVL": "0"}, {"SF_OVL": "2"},
     {"SF_TRAP": "0"}, {"SF_TRAP": "2"}, {"SF_TRAP": "5"},
     {"SF_HALO_STREAM": "1"}, {"SF_HALO_STREAM": "2"},

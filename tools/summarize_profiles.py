@@ -15,8 +15,23 @@ src = os.path.join(ROOT, "gpurun_out", f"profiles_{tag}")
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
 
+
+
+def newest(pattern):
+    """gpurun MERGES a call's output into the local gpurun_out/: a second collection leaves the first one's files
+    (named by process id) beside its own. Only the newest process's files of a directory count."""
+    by_dir = defaultdict(list)
+    for f in glob.glob(pattern, recursive=True):
+        by_dir[os.path.dirname(f)].append(f)
+    out = []
+    for fs in by_dir.values():
+        pid = os.path.basename(max(fs, key=os.path.getmtime)).split("_")[0]
+        out += [f for f in fs if os.path.basename(f).split("_")[0] == pid]
+    return out
+
+
 shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, f"{tag}_bench.json"))
-for f in glob.glob(os.path.join(src, "bench_stats", "**", "*kernel_stats.csv"), recursive=True):
+for f in newest(os.path.join(src, "bench_stats", "**", "*kernel_stats.csv")):
     shutil.copy(f, os.path.join(dst, f"{tag}_bench_kernel_stats.csv"))
 if os.path.exists(os.path.join(src, "rank_share.jsonl")):
     shutil.copy(os.path.join(src, "rank_share.jsonl"), os.path.join(dst, f"{tag}_rank_share.jsonl"))
@@ -24,7 +39,7 @@ if os.path.exists(os.path.join(src, "rank_share.jsonl")):
 
 def counters(path):
     acc = defaultdict(lambda: defaultdict(list))
-    for f in glob.glob(os.path.join(path, "**", "*counter_collection.csv"), recursive=True):
+    for f in newest(os.path.join(path, "**", "*counter_collection.csv")):
         for row in csv.DictReader(open(f)):
             acc[row["Kernel_Name"].split("(")[0]][row["Counter_Name"]].append(float(row["Counter_Value"]))
     return acc
@@ -32,7 +47,7 @@ def counters(path):
 
 def kernel_avg_ns(path):
     out = {}
-    for f in glob.glob(os.path.join(path, "**", "*kernel_stats.csv"), recursive=True):
+    for f in newest(os.path.join(path, "**", "*kernel_stats.csv")):
         for row in csv.DictReader(open(f)):
             out[row["Name"].split("(")[0]] = (int(row["Calls"]), float(row["AverageNs"]))
     return out
