@@ -1926,14 +1926,20 @@ private:
             if (advect_lds_ && m.gx == 1 && lds <= 64 * 1024)
                 hipLaunchKernelGGL((sfk::advect_lds_kernel<T, NF>), dim3(nblocks), block, lds, sl.cur, sl.geom, A, kb,
                                    ke, m, rs);
-            else if (advect_row_ >= 2 || (advect_row_ == 1 && NF >= 2 && sizeof(T) == 4)) {
-                // one cell per lane, the i0+1 samples from the neighbour lane: the three velocity components in fp32
-                // (256^3 245 -> 176 us, 512^3 1628 -> 1217). One field: 79 -> 88 / 572 -> 662, fp64: 350 -> 399 /
-                // 2418 -> 2826 — the gather form stays there. SF_ADVECT_ROW=0 / 2: never / always.
+            else if (advect_row_ >= 2 || (advect_row_ == 1 && NF >= 2)) {
+                // one cell per lane for the three velocity components. fp32: the i0+1 samples from the neighbour lane
+                // (256^3 245 -> 171 us, 512^3 1628 -> 1217; with own (i0, i0+1) pair loads 215 / 1537). fp64: own pair
+                // loads (256^3 376 -> 307 us; with neighbour-lane sharing 415). One field: the gather form stays
+                // (fp32 79 vs 88 / 113, fp64 130 vs 150 / 129). SF_ADVECT_ROW = 0 never, 2 / 3 always the sharing /
+                // the pair form.
                 const int wpr = ceil_div(N_, 64);
                 const long waves = (long)wpr * N_ * (ke - kb);
-                hipLaunchKernelGGL((sfk::advect_row_kernel<T, NF>), dim3((unsigned)ceil_div(waves, 4L)), dim3(256), 0,
-                                   sl.cur, sl.geom, A, kb, ke, wpr);
+                if (advect_row_ == 3 || (advect_row_ == 1 && sizeof(T) == 8))
+                    hipLaunchKernelGGL((sfk::advect_row_kernel<T, NF, true>), dim3((unsigned)ceil_div(waves, 4L)),
+                                       dim3(256), 0, sl.cur, sl.geom, A, kb, ke, wpr);
+                else
+                    hipLaunchKernelGGL((sfk::advect_row_kernel<T, NF>), dim3((unsigned)ceil_div(waves, 4L)), dim3(256), 0,
+                                       sl.cur, sl.geom, A, kb, ke, wpr);
             } else
                 hipLaunchKernelGGL((sfk::advect_kernel<T, NF>), dim3(nblocks), block, 0, sl.cur, sl.geom, A, kb, ke, m);
         }, 1, true, /*interior_reads_ghosts=*/true);  // a long back-trace may reach a ghost plane from any plane
@@ -1997,7 +2003,7 @@ private:
     T dt_{}, diff_{}, visc_{};
     int num_cu_ = 256;
     int nzl_ = 0, lead_ = 0, px_ = 0, nplanes_ = 0, kchunk_ = 0, jacobi_mode_ = 2, tx_override_ = 0, nt_mode_ = 2, rb_shape_ = 0;
-    int advect_row_ = 1;  // 0 gather form always, 1 one cell per lane for the three velocity components, 2 always
+    int advect_row_ = 1;  // 0 gather form always, 1 one cell per lane for the three velocity components, 2 / 3 always
     bool ishell_skip_ = true, advect_lds_ = false, zero_skip_ = true, x_is_zero_ = false, fuse_src_ = true;
     int fuse2_ = 1, kc2_ = 32;
     int march_k_ = 1, march_min_planes_ = 12;

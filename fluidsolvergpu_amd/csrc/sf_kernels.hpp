@@ -2012,8 +2012,9 @@ __global__ void __launch_bounds__(256) advect_kernel(Geom g, AdvectArgs<T, NF> A
 // landed elsewhere, and lane 63, load their own i0+1 samples under an exec mask. (Waves of 63 cells whose lane 63 only
 // feeds, so that the masked loads are skipped in most waves, measured slower: 204 vs 176 us — rows no longer start on
 // a line.) Same values, same expressions as advect_kernel: bit-identical.
-template <class T, int NF>
+template <class T, int NF, bool PAIRS = false>
 __global__ void __launch_bounds__(256) advect_row_kernel(Geom g, AdvectArgs<T, NF> A, int kb, int ke, int wpr) {
+    typedef T Pair __attribute__((ext_vector_type(2), aligned(sizeof(T))));
     const int lane = (int)threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)blockIdx.x * 4 + ((int)threadIdx.x >> 6));
     const int N = g.N;
@@ -2058,11 +2059,24 @@ __global__ void __launch_bounds__(256) advect_row_kernel(Geom g, AdvectArgs<T, N
     const bool shared = pn == p00 + 1;
     const long off[4] = {0, g.plane, g.px, g.px + g.plane};
     T c0[NF][4], c1[NF][4] = {};
+    if constexpr (PAIRS) {
+        // every lane loads the (i0, i0+1) pair itself — 2 cells per lane at a one-cell stride, no shifts, no masked
+        // loads: the better form in fp64 (16 bytes per lane: 307 vs 415 us at 256^3), the worse one in fp32 (215 vs 171)
+#pragma unroll
+        for (int f = 0; f < NF; ++f)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const Pair pr = *reinterpret_cast<const Pair*>(A.d0[f] + p00 + off[c]);
+                c0[f][c] = pr[0];
+                c1[f][c] = pr[1];
+            }
+    } else {
 #pragma unroll
     for (int f = 0; f < NF; ++f)
 #pragma unroll
         for (int c = 0; c < 4; ++c) c0[f][c] = A.d0[f][p00 + off[c]];
-    if (!shared) {
+    }
+    if (!PAIRS && !shared) {
 #pragma unroll
         for (int f = 0; f < NF; ++f)
 #pragma unroll
@@ -2073,8 +2087,10 @@ __global__ void __launch_bounds__(256) advect_row_kernel(Geom g, AdvectArgs<T, N
     for (int f = 0; f < NF; ++f) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const T nb = lane_dn(c0[f][c]);
-            c1[f][c] = shared ? nb : c1[f][c];
+            if constexpr (!PAIRS) {
+                const T nb = lane_dn(c0[f][c]);
+                c1[f][c] = shared ? nb : c1[f][c];
+            }
         }
         T out[1];
         out[0] = s0 * (t0 * (r0 * c0[f][0] + r1 * c0[f][1]) + t1 * (r0 * c0[f][2] + r1 * c0[f][3])) +

@@ -158,13 +158,14 @@ def test_lin_solve_zero_iters_is_noop(dtype):
         assert_same(fs.download("dens"), f["dens"], "K=0")
 
 
-@pytest.fixture(params=["default", "gather", "row"])
+@pytest.fixture(params=["default", "gather", "row", "pairs"])
 def advect_form(request, monkeypatch):
-    """advect has two forms: per-cell gathers of (i0, i0+1) pairs, and one cell per lane with the i0+1 samples taken
-    from the neighbour lane (by default only for the three velocity components in fp32). SF_ADVECT_ROW = 0 / 2 force
-    one or the other for every call, so both forms see every size, dtype and boundary mode of these tests."""
+    """advect has three forms: four cells per thread with per-cell gathers of (i0, i0+1) pairs; one cell per lane with
+    the i0+1 samples taken from the neighbour lane; one cell per lane with own pair loads. By default the second / third
+    serve the three velocity components in fp32 / fp64 and the first everything else. SF_ADVECT_ROW = 0 / 2 / 3 force
+    one form for every call, so each sees every size, dtype and boundary mode of these tests."""
     if request.param != "default":
-        monkeypatch.setenv("SF_ADVECT_ROW", "0" if request.param == "gather" else "2")
+        monkeypatch.setenv("SF_ADVECT_ROW", {"gather": "0", "row": "2", "pairs": "3"}[request.param])
     return request.param
 
 
