@@ -176,8 +176,10 @@ public:
             const int ghost_max = env_int("SF_GHOST", 4), smax = env_int("SF_SK_S", 4);
             for (int gs = 3; gs <= 4; ++gs) {  // S = gs sweeps per exchange need gs ghost planes
                 const int interior = nzl_ - 2 * gs;
-                if (G_ == gs - 1 && ghost_max >= gs && env_int("SF_MARCH", 1) != 0 && smax >= gs &&
-                    env_int("SF_SPLIT", 1) != 0 && interior >= env_int("SF_MARCH_MINP", 12) &&
+                // (SF_ISHELL=0 — every sweep reads and writes the i-shell in memory — rules the marching kernel out:
+                // then nothing would use the deeper ghost zone, and the pair-only schedules are only exercised on two)
+                if (G_ == gs - 1 && ghost_max >= gs && env_int("SF_MARCH", 1) != 0 && env_int("SF_ISHELL", 1) != 0 &&
+                    smax >= gs && env_int("SF_SPLIT", 1) != 0 && interior >= env_int("SF_MARCH_MINP", 12) &&
                     (long)N_ * N_ * interior >= min_cells)
                     G_ = gs;
             }

@@ -16,6 +16,7 @@ SWITCHES = [
     {"SF_SK_FIRST": "0"},           # first pass of a solve through the register-blocked pair kernel
     {"SF_SK_LINEAR": "1"},          # single-round marching launches deal column blocks to the XCDs one by one
     {"SF_FUSE2": "0"},              # single sweeps, one ghost plane
+    {"SF_ISHELL": "0"},             # i-shell read and written by every sweep (no marching kernel, two ghost planes)
     {"SF_ADVECT_ROW": "0"}, {"SF_ADVECT_ROW": "2"}, {"SF_ADVECT_ROW": "3"},  # advect: one form for every call
     {"SF_OVL": "0"}, {"SF_OVL": "2"},
     {"SF_TRAP": "0"}, {"SF_TRAP": "2"}, {"SF_TRAP": "5"},
