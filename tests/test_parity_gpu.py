@@ -303,7 +303,10 @@ def test_slabs_full_step_bit_identical(N, P, transport, dtype):
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "f64"])
 @pytest.mark.parametrize("transport", TRANSPORTS)
-@pytest.mark.parametrize("N,P,K,steps", [(64, 2, 7, 2), (64, 8, 6, 1), (48, 4, 4, 2), (128, 4, 5, 1)])
+@pytest.mark.parametrize("N,P,K,steps", [(64, 2, 7, 2), (64, 8, 6, 1), (48, 4, 4, 2), (128, 4, 5, 1),
+                                         # solves that end in (or consist of) a single sweep or a pair on slabs deep
+                                         # enough for three / four ghost planes under "marching"
+                                         (128, 4, 1, 1), (128, 4, 2, 1), (96, 4, 9, 1), (128, 2, 13, 1), (96, 2, 3, 2)])
 def test_slabs_fused_pairs_two_ghost_planes(N, P, K, steps, transport, dtype, march_mode):
     """N % vector width == 0 and >= 2 planes per slab: sweep pairs are fused across slab boundaries (two ghost
     planes, one exchange per pair, div recomputed on the first ghost plane). Must still equal the oracle."""
