@@ -301,47 +301,6 @@ struct JacobiArgs {
     T dt;
 };
 
-template <class T, int NF>
-__global__ void __launch_bounds__(256) jacobi_kernel(Geom g, JacobiArgs<T, NF> A, int kb, int ke,
-                                                      int kchunk) {
-    constexpr int W = VecT<T>::W;
-    typedef typename VecT<T>::type V;
-    int i0, j, nv;
-    if (!thread_cell<W>(g, i0, j, nv)) return;
-    const int k0 = kb + (int)blockIdx.z * kchunk;
-    const int k1 = (k0 + kchunk < ke) ? k0 + kchunk : ke;
-    if (k0 >= k1) return;
-    const T a = A.a, inv = A.inv;
-#pragma unroll
-    for (int f = 0; f < NF; ++f) {
-        const T* __restrict__ x = A.x[f];
-        const T* __restrict__ x0 = A.x0[f];
-        T* __restrict__ xn = A.xn[f];
-        long q = row0(g, j, k0) + i0;
-        V km = ldv(x + q - g.plane);
-        V c = ldv(x + q);
-        for (int kl = k0; kl < k1; ++kl, q += g.plane) {
-            const V kp = ldv(x + q + g.plane);
-            const V jm = ldv(x + q - g.px);
-            const V jp = ldv(x + q + g.px);
-            const V s = ldv(x0 + q);
-            const T xm = x[q - 1];
-            const T xp = x[q + W];
-            T out[W];
-#pragma unroll
-            for (int e = 0; e < W; ++e) {
-                const T left = (e == 0) ? xm : c[e - 1];
-                const T right = (e == W - 1) ? xp : c[e + 1];
-                out[e] = (s[e] + a * (((left + right) + (jm[e] + jp[e])) + (km[e] + kp[e]))) * inv;
-            }
-            store_cells<T, W>(xn, q - i0, i0, out, nv);
-            emit_shells<T, W>(xn, g, A.b[f], i0, j, kl, out, nv);
-            km = c;
-            c = kp;
-        }
-    }
-}
-
 // Register-blocked flat sweep (the production Jacobi kernel).
 //   * 1-D grid in memory order, one workgroup = (tx lanes x W cells) x (ty*RJ rows) x RK planes, so the
 //     lines in flight form a compact moving window (what a plain copy needs to reach ~6.2 TB/s here);
@@ -1695,220 +1654,6 @@ __global__ void __launch_bounds__(64 * NW, SF_SK_WAVES) jacobi_sk_kernel(Geom g,
                                                            wave, lane, first_vec, last_vec, x0out, A.dt);
 }
 
-// LDS-staged, k-marching form of the two-sweep kernel (2.5-D temporal blocking).
-// A workgroup of NV x 4 threads (NV = vectors per row rounded up to 64) owns TJ output rows of full
-// width and marches `kchunk` planes. Per step it (1) publishes the x rows of plane k+1 (TJ+4 rows,
-// loaded from HBM/L2 exactly once per workgroup) to an LDS tile, (2) computes the first-sweep values
-// y(k+1) on TJ+2 rows — j+-1 from the LDS tile, i+-1 by wave shuffle (LDS only at wave seams),
-// k+-1 from the thread's own registers — and (3) the second-sweep output x''(k) on TJ rows from the
-// y tile of plane k in LDS and y(k-1), y(k), y(k+1) in registers. Loads for the next step are issued
-// before the arithmetic. L2->L1 traffic per output cell and sweep pair: (TJ+4)/TJ of x + (TJ+2)/TJ
-// of x0 (3.0 words at TJ = 8, against ~7.5 for the register-only kernel above); HBM traffic is the
-// compulsory x + x0 + x'' per pair. Walls are handled as in jacobi2_kernel (first-sweep set_bnd
-// applied in registers), so the result is bit-identical to two separate sweeps.
-template <class T, int NF, bool NT, int TJ>
-__global__ void __launch_bounds__(512) jacobi2m_kernel(Geom g, JacobiArgs<T, NF> A, int kb, int ke,
-                                                        TileMap m, int kchunk) {
-    constexpr int W = VecT<T>::W;
-    typedef typename VecT<T>::type V;
-    constexpr int XR = TJ + 4;  // staged rows: tile rows j0-2 .. j0+TJ+1
-    constexpr int RP = 4;       // rows per pass (= blockDim.y)
-    constexpr int NP = XR / RP; // rows per thread
-    static_assert(XR % RP == 0, "TJ + 4 must be a multiple of 4");
-    extern __shared__ __attribute__((aligned(16))) unsigned char sf_smem[];
-    const int NV = (int)blockDim.x;
-    V* __restrict__ Xt = reinterpret_cast<V*>(sf_smem);  // [XR][NV]  x of plane ko+1
-    V* __restrict__ Yt = Xt + XR * NV;                   // [XR][NV]  y of plane ko
-    int jt, kk, f;
-    {
-        int r = (int)blockIdx.x;
-        if (m.band > 0) {
-            const int xcd = r % m.nxcd;
-            r /= m.nxcd;
-            jt = xcd * m.band + r % m.band;
-            r /= m.band;
-        } else {
-            jt = r % m.gy;
-            r /= m.gy;
-        }
-        const int nch = (ke - kb + kchunk - 1) / kchunk;
-        kk = r % nch;
-        f = r / nch;
-    }
-    if (jt >= m.gy) return;  // uniform per workgroup
-    const int N = g.N;
-    const int nvec = N / W;
-    const int k0 = kb + kk * kchunk;
-    const int k1 = (k0 + kchunk < ke) ? k0 + kchunk : ke;
-    const int v = (int)threadIdx.x, h = (int)threadIdx.y, lane = v & 63;
-    const bool vact = v < nvec;
-    const int vc = vact ? v : nvec - 1;  // lanes beyond the row work on a clamped copy, store nothing
-    const int i0 = 1 + W * vc;
-    const int j0 = 1 + jt * TJ;
-    const T a = A.a, inv = A.inv;
-    const T* __restrict__ x = A.x[0];
-    const T* __restrict__ x0 = A.x0[0];
-    T* __restrict__ xn = A.xn[0];
-    int b = A.b[0];
-#pragma unroll
-    for (int ff = 1; ff < NF; ++ff)
-        if (f == ff) {
-            x = A.x[ff];
-            x0 = A.x0[ff];
-            xn = A.xn[ff];
-            b = A.b[ff];
-        }
-    const T sx = (b == 1) ? T(-1) : T(1);
-    const T sy = (b == 2) ? T(-1) : T(1);
-    const T sz = (b == 3) ? T(-1) : T(1);
-    const bool first_vec = (v == 0), last_vec = (v == nvec - 1);
-
-    long rowq[NP];
-    int jrow[NP];
-#pragma unroll
-    for (int p = 0; p < NP; ++p) {
-        const int j = j0 - 2 + h + RP * p;
-        jrow[p] = j;
-        const int jc = j < 0 ? 0 : (j > N + 1 ? N + 1 : j);
-        rowq[p] = (long)jc * g.px + (g.lead - 1) + i0;
-    }
-    const int kmax = g.np - 1;
-    auto planeq = [&](int kl) -> long {
-        kl = kl < 0 ? 0 : (kl > kmax ? kmax : kl);
-        return (long)kl * g.plane;
-    };
-
-    V xA[NP], xB[NP], xC[NP], xD[NP], yA[NP], yB[NP], yC[NP], sB[NP], sC[NP], sD[NP];
-    {
-        const long pa = planeq(k0 - 2), pb = planeq(k0 - 1), pc = planeq(k0);
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
-            xA[p] = ldv(x + pa + rowq[p]);
-            xB[p] = ldv(x + pb + rowq[p]);
-            xC[p] = ldv(x + pc + rowq[p]);
-            sC[p] = ldv(x0 + pb + rowq[p]);
-            sB[p] = sC[p];
-            xD[p] = xC[p];
-            sD[p] = sC[p];
-#pragma unroll
-            for (int e = 0; e < W; ++e) {
-                yA[p][e] = T(0);
-                yB[p][e] = T(0);
-                yC[p][e] = T(0);
-            }
-        }
-    }
-
-    for (int ko = k0 - 2; ko < k1; ++ko) {
-        // (1) publish x(ko+1)
-#pragma unroll
-        for (int p = 0; p < NP; ++p) Xt[(h + RP * p) * NV + v] = xB[p];
-        __syncthreads();
-        // (2) loads for the next step, in flight during the arithmetic below
-        if (ko + 1 < k1) {
-            const long pd = planeq(ko + 3), ps = planeq(ko + 2);
-#pragma unroll
-            for (int p = 0; p < NP; ++p) {
-                xD[p] = ldv(x + pd + rowq[p]);
-                sD[p] = ldv(x0 + ps + rowq[p]);
-            }
-        }
-        // (3) first sweep: y(ko+1) on tile rows 1 .. TJ+2
-        const long pq = planeq(ko + 1);
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
-            const int r = h + RP * p;
-            const int j = jrow[p];
-            if (r < 1 || r > TJ + 2 || j < 1 || j > N) continue;  // uniform per wave
-            const V cc = xB[p];
-            const T up = lane_up(cc[W - 1]);
-            const T dn = lane_dn(cc[0]);
-            T xm, xp;
-            if (first_vec)
-                xm = m.ishell_mem ? x[pq + rowq[p] - 1] : sx * cc[0];
-            else
-                xm = (lane != 0) ? up : Xt[r * NV + v - 1][W - 1];
-            if (last_vec)
-                xp = m.ishell_mem ? x[pq + rowq[p] + W] : sx * cc[W - 1];
-            else
-                xp = (lane != 63) ? dn : (v + 1 < nvec ? Xt[r * NV + v + 1][0] : cc[W - 1]);
-            const V jm = Xt[(r - 1) * NV + v], jp = Xt[(r + 1) * NV + v];
-            const V km = xA[p], kp = xC[p], s = sC[p];
-            V y;
-#pragma unroll
-            for (int e = 0; e < W; ++e) {
-                const T left = (e == 0) ? xm : cc[e - 1];
-                const T right = (e == W - 1) ? xp : cc[e + 1];
-                y[e] = (s[e] + a * (((left + right) + (jm[e] + jp[e])) + (km[e] + kp[e]))) * inv;
-            }
-            yC[p] = y;
-        }
-        // (4) second sweep: x''(ko) on tile rows 2 .. TJ+1
-        if (ko >= k0) {
-            const int kg = g.kg0 + ko;
-            const long po = planeq(ko);
-#pragma unroll
-            for (int p = 0; p < NP; ++p) {
-                const int r = h + RP * p;
-                const int j = jrow[p];
-                if (r < 2 || r > TJ + 1 || j < 1 || j > N) continue;  // uniform per wave
-                const V yc = yB[p];
-                const T up = lane_up(yc[W - 1]);
-                const T dn = lane_dn(yc[0]);
-                T ym, yp;
-                if (first_vec)
-                    ym = sx * yc[0];
-                else
-                    ym = (lane != 0) ? up : Yt[r * NV + v - 1][W - 1];
-                if (last_vec)
-                    yp = sx * yc[W - 1];
-                else
-                    yp = (lane != 63) ? dn : (v + 1 < nvec ? Yt[r * NV + v + 1][0] : yc[W - 1]);
-                V jm = Yt[(r - 1) * NV + v], jp = Yt[(r + 1) * NV + v];
-                V km = yA[p], kp = yC[p];
-                if (j == 1) jm = sy * yc;
-                if (j == N) jp = sy * yc;
-                if (g.wall_lo && kg == 1) km = sz * yc;
-                if (g.wall_hi && kg == N) kp = sz * yc;
-                const V s = sB[p];
-                T out[W];
-#pragma unroll
-                for (int e = 0; e < W; ++e) {
-                    const T left = (e == 0) ? ym : yc[e - 1];
-                    const T right = (e == W - 1) ? yp : yc[e + 1];
-                    out[e] = (s[e] + a * (((left + right) + (jm[e] + jp[e])) + (km[e] + kp[e]))) * inv;
-                }
-                if (vact) {
-                    const long q = po + rowq[p];
-                    V o;
-#pragma unroll
-                    for (int e = 0; e < W; ++e) o[e] = out[e];
-                    if (NT)
-                        __builtin_nontemporal_store(o, reinterpret_cast<V*>(xn + q));
-                    else
-                        stv(xn + q, o);
-                    const bool near_wall = first_vec | last_vec | (j == 1) | (j == N) |
-                                           (g.wall_lo && kg == 1) | (g.wall_hi && kg == N);
-                    if (near_wall) emit_shells_call<T, W>(xn, g, b, i0, j, ko, o, m.ishell_write != 0);
-                }
-            }
-        }
-        // (5) everyone is done with the y tile of plane ko and the x tile of plane ko+1
-        __syncthreads();
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
-            Yt[(h + RP * p) * NV + v] = yC[p];
-            xA[p] = xB[p];
-            xB[p] = xC[p];
-            xC[p] = xD[p];
-            yA[p] = yB[p];
-            yB[p] = yC[p];
-            sB[p] = sC[p];
-            sC[p] = sD[p];
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
 // advect: semi-Lagrangian back-trace + trilinear interpolation + fused set_bnd (SPEC §3 advect).
 // NF fields share one back-trace (vel_step advects u,v,w through the same velocity).
@@ -2101,150 +1846,6 @@ __global__ void __launch_bounds__(256) advect_row_kernel(Geom g, AdvectArgs<T, N
         }
     }
     if (bad) atomicOr(A.flag, 1);
-}
-
-// LDS-staged advect (opt-in, SF_ADVECT_LDS=1; a measured NEGATIVE result kept for the record: 1.5x slower than
-// advect_kernel at 256^3). The gathers of advect_kernel are texture-address bound (12 two-wide gathers per cell and
-// field). Here a workgroup (one whole-row tile: tx = N/W lanes x ty rows of one plane) first stages, per field,
-// the rows jb-1 .. jb+ty of planes kl-1 .. kl+1 in LDS with coalesced 16-byte loads, then takes the eight
-// trilinear samples from LDS. That covers every back-trace of less than one cell (the benchmark's are <= 1/2);
-// if any cell of the tile reaches further the whole workgroup takes the global-memory path, so results never
-// depend on which path ran. Same expressions as advect_kernel: bit-identical.
-template <class T, int NF>
-__global__ void __launch_bounds__(256) advect_lds_kernel(Geom g, AdvectArgs<T, NF> A, int kb, int ke, TileMap m,
-                                                         int rs) {
-    constexpr int W = VecT<T>::W;
-    typedef typename VecT<T>::type V;
-    typedef T Pair __attribute__((ext_vector_type(2), aligned(sizeof(T))));
-    extern __shared__ __attribute__((aligned(16))) unsigned char sf_smem[];
-    T* __restrict__ tile = reinterpret_cast<T*>(sf_smem);  // [3][ty+2][rs], cell i of a row at index i + 3
-    int it, jt, kk, fdummy;
-    if (!flat_tile(m, ke - kb, it, jt, kk, fdummy)) return;  // uniform per workgroup
-    const int kl = plane_of(m, kb, kk);
-    const int N = g.N;
-    const int ty = (int)blockDim.y;
-    const int nvec = (N + W - 1) / W;
-    const int jb = 1 + jt * ty;
-    const int v = (int)threadIdx.x;
-    const int i0 = 1 + W * v;
-    const int j = jb + (int)threadIdx.y;
-    const bool cell_ok = (v < nvec) && (j <= N);
-    int nv = N - i0 + 1;
-    nv = nv > W ? W : (nv < 0 ? 0 : nv);
-    const T Nf = (T)N;
-    const T lo = T(0.5), hi = Nf + T(0.5);
-    const int kg = g.kg0 + kl;
-    const long q = row0(g, j <= N ? j : N, kl) + (v < nvec ? i0 : 1);
-
-    // ---- back-trace (shared by the NF fields) ------------------------------------------------------------
-    int ia[W], jr[W], kz[W], kla[W], jaa[W];
-    T s1[W], t1[W], r1[W];
-    bool near = true, bad = false;
-    {
-        V uu, vv, ww;
-        if (cell_ok) {
-            uu = ldv(A.u + q);
-            vv = ldv(A.v + q);
-            ww = ldv(A.w + q);
-        }
-#pragma unroll
-        for (int e = 0; e < W; ++e) {
-            ia[e] = 1; jr[e] = 1; kz[e] = 1; kla[e] = kl; jaa[e] = 1;
-            s1[e] = t1[e] = r1[e] = T(0);
-            if (!cell_ok || e >= nv) continue;
-            T x = (T)(i0 + e) - A.dt0 * uu[e];
-            T y = (T)j - A.dt0 * vv[e];
-            T z = (T)kg - A.dt0 * ww[e];
-            if (x < lo) x = lo;
-            if (x > hi) x = hi;
-            if (y < lo) y = lo;
-            if (y > hi) y = hi;
-            if (z < lo) z = lo;
-            if (z > hi) z = hi;
-            int a = (x == x) ? (int)x : 0;
-            int b = (y == y) ? (int)y : 0;
-            int c = (z == z) ? (int)z : 0;
-            a = a < 0 ? 0 : (a > N ? N : a);
-            b = b < 0 ? 0 : (b > N ? N : b);
-            c = c < 0 ? 0 : (c > N ? N : c);
-            s1[e] = x - (T)a;
-            t1[e] = y - (T)b;
-            r1[e] = z - (T)c;
-            int cl = c - g.kg0;
-            if (cl < 0 || cl > g.np - 2) {
-                bad = true;
-                cl = cl < 0 ? 0 : g.np - 2;
-            }
-            ia[e] = a;
-            jaa[e] = b;
-            kla[e] = cl;
-            jr[e] = b - (jb - 1);        // tile row of j0: rows 0 .. ty+1 hold jb-1 .. jb+ty
-            kz[e] = cl - (kl - 1);       // tile plane of k0: planes 0 .. 2 hold kl-1 .. kl+1
-            if (jr[e] < 0 || jr[e] > ty || kz[e] < 0 || kz[e] > 1) near = false;
-        }
-    }
-    if (bad) atomicOr(A.flag, 1);
-    const bool use_lds = __syncthreads_and(near ? 1 : 0) != 0;
-
-    T out[NF][W];
-#pragma unroll
-    for (int f = 0; f < NF; ++f) {
-        const T* __restrict__ d0 = A.d0[f];
-        if (use_lds) {
-            // stage planes kl-1..kl+1, rows jb-1..jb+ty (clamped into the stored range; clamped rows are never read)
-            const int nrows = 3 * (ty + 2);
-            for (int r0 = 0; r0 < nrows; r0 += ty) {
-                const int r = r0 + (int)threadIdx.y;
-                if (r < nrows && v < nvec) {
-                    const int pz = r / (ty + 2), pr = r - pz * (ty + 2);
-                    int jj = jb - 1 + pr;
-                    jj = jj > N + 1 ? N + 1 : jj;
-                    int kq = kl - 1 + pz;
-                    kq = kq < 0 ? 0 : (kq > g.np - 1 ? g.np - 1 : kq);
-                    const long src = row0(g, jj, kq);
-                    T* dst = tile + (long)r * rs + 3;
-                    *reinterpret_cast<V*>(dst + i0) = ldv(d0 + src + i0);  // cells i0 .. i0+W-1 (pads beyond N+1)
-                    if (v == 0) dst[0] = d0[src];
-                    if (v == nvec - 1 && i0 + W - 1 < N + 1) dst[N + 1] = d0[src + N + 1];
-                }
-            }
-            __syncthreads();
-#pragma unroll
-            for (int e = 0; e < W; ++e) {
-                out[f][e] = T(0);
-                if (!cell_ok || e >= nv) continue;
-                const T s0 = T(1) - s1[e], t0 = T(1) - t1[e], r0w = T(1) - r1[e];
-                const T* p00 = tile + ((long)(kz[e] * (ty + 2) + jr[e])) * rs + 3 + ia[e];
-                const T* p01 = p00 + (long)(ty + 2) * rs;
-                const T* p10 = p00 + rs;
-                const T* p11 = p10 + (long)(ty + 2) * rs;
-                out[f][e] = s0 * (t0 * (r0w * p00[0] + r1[e] * p01[0]) + t1[e] * (r0w * p10[0] + r1[e] * p11[0])) +
-                            s1[e] * (t0 * (r0w * p00[1] + r1[e] * p01[1]) + t1[e] * (r0w * p10[1] + r1[e] * p11[1]));
-            }
-            __syncthreads();  // the tile is reused by the next field
-        } else {
-#pragma unroll
-            for (int e = 0; e < W; ++e) {
-                out[f][e] = T(0);
-                if (!cell_ok || e >= nv) continue;
-                const T s0 = T(1) - s1[e], t0 = T(1) - t1[e], r0w = T(1) - r1[e];
-                const long p00 = row0(g, jaa[e], kla[e]) + ia[e];
-                const long p01 = p00 + g.plane, p10 = p00 + g.px, p11 = p10 + g.plane;
-                const Pair c00 = *reinterpret_cast<const Pair*>(d0 + p00);
-                const Pair c01 = *reinterpret_cast<const Pair*>(d0 + p01);
-                const Pair c10 = *reinterpret_cast<const Pair*>(d0 + p10);
-                const Pair c11 = *reinterpret_cast<const Pair*>(d0 + p11);
-                out[f][e] = s0 * (t0 * (r0w * c00[0] + r1[e] * c01[0]) + t1[e] * (r0w * c10[0] + r1[e] * c11[0])) +
-                            s1[e] * (t0 * (r0w * c00[1] + r1[e] * c01[1]) + t1[e] * (r0w * c10[1] + r1[e] * c11[1]));
-            }
-        }
-    }
-    if (!cell_ok) return;
-#pragma unroll
-    for (int f = 0; f < NF; ++f) {
-        store_cells<T, W>(A.d[f], q - i0, i0, out[f], nv);
-        emit_shells<T, W>(A.d[f], g, A.b[f], i0, j, kl, out[f], nv);
-    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2476,7 +2077,7 @@ struct HaloCopyArgs {
     long n16;  // 16-byte units per segment
 };
 
-__global__ void __launch_bounds__(256) halo_copy_kernel(HaloCopyArgs A) {
+static __global__ void __launch_bounds__(256) halo_copy_kernel(HaloCopyArgs A) {
     const int seg = (int)blockIdx.y;
     if (seg >= A.nseg) return;
     const float4* __restrict__ s = A.src[0];
@@ -2492,7 +2093,7 @@ __global__ void __launch_bounds__(256) halo_copy_kernel(HaloCopyArgs A) {
 }
 
 // float4 copy used to quote the achievable HBM rate in the same run as the solver numbers.
-__global__ void __launch_bounds__(256) copy16_kernel(const float4* __restrict__ src,
+static __global__ void __launch_bounds__(256) copy16_kernel(const float4* __restrict__ src,
                                                      float4* __restrict__ dst, long n) {
     const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (q < n) dst[q] = src[q];

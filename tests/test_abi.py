@@ -49,7 +49,7 @@ def test_gpu_code_object_is_gfx950():
                           os.path.join(ROOT, "fluidsolvergpu_amd", "libsfgpu.so")],
                          capture_output=True, text=True).stdout
     raw = open(os.path.join(ROOT, "fluidsolvergpu_amd", "libsfgpu.so"), "rb").read()
-    assert b"gfx950" in raw and b"jacobi_kernel" in raw, out[:200]
+    assert b"gfx950" in raw and b"jacobi_sk_kernel" in raw and b"advect_row_kernel" in raw, out[:200]
 
 
 def _has_gpu():

@@ -210,10 +210,9 @@ def test_advect_smooth_flow(N, b, dtype, advect_form):
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "f64"])
 @pytest.mark.parametrize("mode", ["near", "mixed"])
 @pytest.mark.parametrize("N,b", [(1, 0), (3, 1), (8, 2), (13, 3), (32, 1), (64, 0), (100, 2)])
-def test_advect_lds_path(N, b, mode, dtype, monkeypatch):
-    """(opt-in kernel, SF_ADVECT_LDS=1) Back-traces shorter than one cell take the LDS-staged path; 'mixed' puts a few long back-traces into some
-    tiles so both paths run in one launch. Either way the result must equal the oracle."""
-    monkeypatch.setenv("SF_ADVECT_LDS", "1")
+def test_advect_short_and_long_backtraces(N, b, mode, dtype):
+    """Back-traces shorter than one cell ('near'), and 'mixed': a few long back-traces (several cells, clamped at the
+    walls) scattered into the field. Either way the result must equal the oracle."""
     rng = np.random.RandomState(60 + N)
     f = rand_fields(N, dtype, 61)
     lim = 0.95 / (DT * N)
@@ -230,7 +229,7 @@ def test_advect_lds_path(N, b, mode, dtype, monkeypatch):
         got = fs.download("dens")
     want = f["dens"].copy()
     O.advect(b, want, f["dens0"], f["u"], f["v"], f["w"], dtype(DT))
-    assert_same(got, want, f"advect(lds,{mode}) b={b}")
+    assert_same(got, want, f"advect({mode}) b={b}")
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "f64"])

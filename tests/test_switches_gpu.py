@@ -14,9 +14,12 @@ SWITCHES = [
     {"SF_MARCH": "0"},              # register-blocked pair kernel everywhere
     {"SF_SK_S": "2"}, {"SF_SK_S": "3"},  # marching kernel limited to two / three sweeps per pass
     {"SF_SK_FIRST": "0"},           # first pass of a solve through the register-blocked pair kernel
-    {"SF_SK_LINEAR": "1"},          # single-round marching launches deal column blocks to the XCDs one by one
     {"SF_FUSE2": "0"},              # single sweeps, one ghost plane
-    {"SF_ISHELL": "0"},             # i-shell read and written by every sweep (no marching kernel, two ghost planes)
+    # i-shell read and written by every sweep: no marching launch anywhere (round 2 gated that on one slab only and a
+    # decomposed solve mixed marching passes with pair passes: the SF_ERR_HALO_EXCEEDED of gpurun_out/ish.log); the
+    # slabs keep their four ghost planes, so every pass is a pair launch of boundary depth four
+    {"SF_ISHELL": "0"}, {"SF_ISHELL": "0", "SF_GHOST": "3"}, {"SF_ISHELL": "0", "SF_TRAP": "3"},
+    {"SF_NT": "1"}, {"SF_NT": "0"},  # non-temporal stores everywhere / nowhere (default: beyond the Infinity Cache)
     {"SF_ADVECT_ROW": "0"}, {"SF_ADVECT_ROW": "2"}, {"SF_ADVECT_ROW": "3"},  # advect: one form for every call
     {"SF_OVL": "0"}, {"SF_OVL": "2"},
     {"SF_TRAP": "0"}, {"SF_TRAP": "2"}, {"SF_TRAP": "5"},
@@ -24,8 +27,12 @@ SWITCHES = [
     {"SF_SPLIT_FIELDS": "0"}, {"SF_SPLIT_FIELDS": "2"},
     {"SF_GHOST": "1"}, {"SF_GHOST": "2"}, {"SF_GHOST": "3"},
     {"SF_FUSE_SRC": "0"}, {"SF_ZERO_SKIP": "0"}, {"SF_SPLIT": "0"},
+    {"SF_MARCH_MINP": "4"},         # thin slabs through the marching kernel
+    {"SF_AUTOTUNE": "0"},           # rccl-self contexts keep the default schedule instead of measuring one
     {"SF_MARCH": "0", "SF_TRAP": "3", "SF_HALO_STREAM": "2", "SF_SPLIT_FIELDS": "0"},
 ]
+# (SF_GRAPH: test_parity_gpu.py::test_graph_replay_matches; SF_MARCH_MINCELLS_K: the march_mode fixture there and below;
+# SF_TRACE_SCHEDULE: tests/test_schedule_trace.py)
 
 
 def run_case(N, P, K, steps, transport="copy"):
@@ -58,8 +65,10 @@ def test_switch_settings_against_the_oracle(env, monkeypatch):
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     monkeypatch.setenv("SF_MARCH_MINCELLS_K", "100")  # let the marching kernel take these small grids too
+    # the last two: deep slabs (four ghost planes) whose solves are pair launches only by default (K < 7) - the schedule
+    # round 2's SF_ISHELL=0 failure was wrongly blamed on
     for N, P, K, steps, transport in ((64, 1, 7, 2, "copy"), (72, 1, 20, 1, "copy"), (64, 4, 6, 1, "copy"), (96, 2, 11, 1, "rccl-self"),
-                                      (96, 3, 20, 1, "copy")):
+                                      (96, 3, 20, 1, "copy"), (96, 2, 4, 1, "copy"), (96, 2, 6, 2, "rccl-self")):
         got, want = run_case(N, P, K, steps, transport)
         for n in got:
             assert_same(got[n], want[n], f"{env} N={N} P={P} K={K} {transport}: {n}")
