@@ -136,6 +136,7 @@ def time_lin_solve(S, N, dtype, K, reps, device):
             per.append(fs.timer_stop() * 1e3 / launches)
         fs.sync()
         return {"us_per_launch": float(np.mean(per)), "us_per_launch_min": float(np.min(per)),
+                "us_per_launch_median": float(np.median(per)), "timed_solves": reps,
                 "sweeps_per_launch": K / launches, "launches_per_solve": launches,
                 "us_per_sweep_whole_solve": float(np.mean(per)) * launches / K}
 
@@ -147,6 +148,7 @@ def cpu_baseline(N, K, dtype, steps, dt, diff, visc):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
 
+    cpu_baseline.fields = None
     npdt = np.float32 if dtype == "f32" else np.float64
     if N > 256:
         rng = np.random.RandomState(3)
@@ -169,6 +171,7 @@ def cpu_baseline(N, K, dtype, steps, dt, diff, visc):
         fields.update({"u0": f["su"].copy(), "v0": f["sv"].copy(), "w0": f["sw"].copy(), "dens0": f["sd"].copy()})
         O.step(N, fields, npdt(dt), npdt(diff), npdt(visc), K)
     el = time.perf_counter() - t0
+    cpu_baseline.fields = fields  # state after `steps` steps: the expected values of parity_in_run
     return {"value": N ** 3 * steps / el / 1e6, "unit": "Mcells/s", "cores": 1, "kind": "port",
             "sample": f"{steps} x (vel_step+dens_step) at {N}^3 {dtype} K={K}, serial C++ oracle "
                       f"(g++ -O2 -ffp-contract=off), {el:.1f} s", "host_cores_visible": os.cpu_count()}
@@ -248,6 +251,26 @@ def main():
     probe = fs.download_planes("dens", kb_o, min(kb_o + 2, ke_o))
     assert np.isfinite(probe).all(), "non-finite density after the timed steps"
 
+    # ---- per-step times (HIP events on the compute stream, one host sync per step): OUTSIDE the timed region above,
+    # whose K steps run back to back as the contract asks; this second loop shows the spread the mean hides ----
+    step_ms = []
+    if world == 1:
+        for _ in range(args.steps):
+            fs.timer_start()
+            step()
+            step_ms.append(fs.timer_stop())
+
+    # ---- parity in this very run: the state the cpu_baseline leg computes below (cpu_steps steps from the benchmark
+    # inputs) computed by the device now, compared bit for bit once the oracle has it ----
+    gpu_after = None
+    want_parity = world == 1 and not args.no_cpu_baseline and N <= 256 and os.environ.get("SF_BENCH_DRYRUN") != "1"
+    if want_parity:
+        upload_inputs(fs, N, dt)
+        for _ in range(args.cpu_steps):
+            step()
+        fs.sync()
+        gpu_after = {n: fs.download(n) for n in ("u", "v", "w", "dens")}
+
     out = None
     if rank == 0:
         cells = float(N) ** 3
@@ -282,12 +305,29 @@ def main():
             "hbm_copy_gbps_same_run": copy_gbps,
             "transport": fs.transport_info() if hasattr(fs, "transport_info") else None,
         }
+        if step_ms:
+            out["step_times_ms"] = {"n": len(step_ms), "min": float(np.min(step_ms)), "median": float(np.median(step_ms)),
+                                    "p90": float(np.percentile(step_ms, 90)), "mean": float(np.mean(step_ms)),
+                                    "note": "HIP events around each step, one host sync per step; a second loop after "
+                                            "the timed region (`ms_per_step` is the back-to-back wall-clock mean)"}
+        # Compulsory traffic of a step: the Jacobi part moves x, x0, x' once per LAUNCH of S fused sweeps (3 words per
+        # cell per launch = 18K/S words over the six solves of a step), the rest as in SURVEY.md §8a (56 words)
+        launches = fs.lin_solve_launches(K) if hasattr(fs, "lin_solve_launches") and K > 0 else 0
+        if launches > 0:
+            spl = K / launches
+            comp_words = 56 + 18.0 * K / spl
+            out["step_compulsory_bytes_per_cell"] = comp_words * wsize
+            out["frac_step_compulsory"] = cells * comp_words * wsize / (elapsed / args.steps) / 1e9 / world / HBM_PEAK_GBPS
     fs.close()
 
     # ---- N > 1: the same grid on ONE GPU (rank 0's), in the same run: the denominator of `speedup` ----
+    if dist is not None:
+        # every rank has released its slab; the ranks other than 0 have nothing left to do: let them go instead of
+        # parking them in a barrier behind rank 0's one-GPU and roofline legs (minutes at 1024^3)
+        dist.barrier()
+        dist.destroy_process_group()
+        dist = None
     if world > 1 and args.single_steps > 0:
-        if dist is not None:
-            dist.barrier()  # every rank has released its slab
         if rank == 0:
             try:
                 with S.FluidSolver(N, dtype=args.dtype, iters=K, dt=dt, diff=diff, visc=visc, device=local_rank) as f1:
@@ -302,11 +342,15 @@ def main():
                         f1.dens_step()
                     f1.sync()
                     t1 = (time.perf_counter() - t0) / args.single_steps
-                out["single_gpu"] = {"grid": N, "steps": args.single_steps, "ms_per_step": t1 * 1e3,
+                out["single_gpu"] = {"grid": N, "steps": args.single_steps, "warmup": 1, "ms_per_step": t1 * 1e3,
                                      "value": float(N) ** 3 / t1 / 1e6, "unit": "Mcells/s",
                                      "note": "same grid, same inputs, rank 0's GPU alone, timed after the distributed phase"}
                 out["speedup"] = out["value"] / out["single_gpu"]["value"]
+                out["speedup_note"] = (f"PROVISIONAL: {args.steps} timed steps after {args.warmup} warm-up over {world} GPUs "
+                                       f"against {args.single_steps} timed steps after 1 warm-up on one GPU; the driver "
+                                       "computes scaling efficiency itself from its N = 1 run")
             except Exception as exc:  # e.g. the grid does not fit one GPU: report, do not fail the run
+                print(f"bench.py: single-GPU leg failed: {type(exc).__name__}: {exc}", file=sys.stderr, flush=True)
                 out["single_gpu"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
                 out["speedup"] = None
 
@@ -317,7 +361,7 @@ def main():
         traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}
 
         def roofline_entry(n):
-            r = time_lin_solve(S, n, args.dtype, K, 5 if n <= 256 else 3, local_rank)
+            r = time_lin_solve(S, n, args.dtype, K, 20, local_rank)  # >= 20 repetitions, min and median
             spl = r["sweeps_per_launch"]
             alg = float(n) ** 3 * 3 * wsize * spl  # 3 words per cell per sweep x sweeps per launch
             us = max(r["us_per_launch"], 1e-9)
@@ -331,12 +375,24 @@ def main():
                             "jacobi_rb_kernel<T,1,*>: one lin_solve sweep + set_bnd per launch"),
                  "achieved": alg / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                  "frac": alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, "grid": n, "us_per_launch": us,
-                 "us_per_launch_min": r["us_per_launch_min"], "sweeps_per_launch": spl,
+                 "us_per_launch_min": r["us_per_launch_min"], "us_per_launch_median": r["us_per_launch_median"],
+                 "timed_solves": r["timed_solves"], "sweeps_per_launch": spl,
+                 "us_per_launch_note": "HIP events around a whole solve / its launches: a per-solve mean over the "
+                                       "first-pass, plain and last-pass variants of the kernel (1 : 3 : 1 at K = 20)",
                  "algorithmic_bytes_per_launch": alg, "launches_per_solve": r["launches_per_solve"],
-                 "us_per_sweep_whole_solve": r["us_per_sweep_whole_solve"]}
+                 "us_per_sweep_whole_solve": r["us_per_sweep_whole_solve"],
+                 # what a launch of S fused sweeps MUST move: x and x0 in, x' out, once (3 words per cell); `frac`
+                 # (SURVEY.md §8d's per-sweep model) counts that S times and is not a fraction of anything for S > 1
+                 "compulsory_bytes_per_launch": alg / spl,
+                 "frac_compulsory": alg / spl / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                 "frac_compulsory_best": alg / spl / (r["us_per_launch_min"] * 1e-6) / 1e9 / HBM_PEAK_GBPS}
             if tr:
                 e["traffic"] = tr["bytes_per_launch"]
-                e["frac_traffic"] = tr["bytes_per_launch"] / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS
+                # counter bytes belong to the PLAIN variant: divide by the kernel-trace time of that same variant from
+                # the same profile when it is recorded (one box, one kernel), else by this run's per-solve mean
+                t_us = tr.get("kernel_trace_us") or us
+                e["frac_traffic"] = tr["bytes_per_launch"] / (t_us * 1e-6) / 1e9 / HBM_PEAK_GBPS
+                e["frac_traffic_time_us"] = t_us
                 e["traffic_provenance"] = {"file": "profiles/traffic_latest.json", "tag": tr.get("tag"),
                                            "source": tr.get("source"), "kernel": tr.get("kernel"),
                                            "note": "FETCH_SIZE x2 + WRITE_SIZE from separate rocprofv3 --pmc passes of an "
@@ -348,9 +404,6 @@ def main():
         hbm_n = args.roofline_n if args.roofline_n else 512
         if hbm_n < 0:
             print(json.dumps(out), flush=True)
-            if dist is not None:
-                dist.barrier()
-                dist.destroy_process_group()
             return
         out["roofline"] = roofline_entry(hbm_n)
         out["roofline"]["note"] = (f"{hbm_n}^3: x, x0 and x' of the solve (3 x {float(hbm_n) ** 3 * wsize / 1e6:.0f} MB) are far "
@@ -366,10 +419,17 @@ def main():
                 "fraction of HBM bandwidth and may exceed 1")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(N, K, args.dtype, args.cpu_steps, dt, diff, visc)
+            want = cpu_baseline.fields
+            if gpu_after is not None and want is not None:
+                # the oracle is the checker here, as in tests/: same inputs, same size, same K, same number of steps
+                names = ("u", "v", "w", "dens")
+                linf = {n: float(np.max(np.abs(gpu_after[n].astype(np.float64) - want[n].astype(np.float64))))
+                        for n in names}
+                out["parity_in_run"] = {"steps": args.cpu_steps, "fields": list(names),
+                                        "bit_exact": bool(all(np.array_equal(gpu_after[n], want[n]) for n in names)),
+                                        "linf": max(linf.values()), "linf_per_field": linf,
+                                        "checker": "serial CPU oracle (oracle/, the cpu_baseline leg's own result)"}
         print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
