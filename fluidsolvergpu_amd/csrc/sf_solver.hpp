@@ -190,6 +190,7 @@ public:
         sk_first_ = env_int("SF_SK_FIRST", 1) != 0;  // first pass of a solve through the marching kernel
         SF_HIP(hipDeviceSynchronize());
         if ((nranks_ > 1 || rccl_self_) && std::getenv("SF_TRAP") == nullptr && env_int("SF_AUTOTUNE", 1)) tune_schedule();
+        trace_open();
     }
 
     // Which trapezoid depth suits THIS machine's halo latency (see the comment at trap_m_)? Times a 20-sweep
@@ -267,6 +268,7 @@ public:
         (void)hipSetDevice(device_);
         (void)hipDeviceSynchronize();
         for (GraphEntry& e : graph_cache_) (void)hipGraphExecDestroy(e.exec);
+        if (trace_) std::fclose(trace_);
         if (comm_) ncclCommDestroy(comm_);
         for (Slab& sl : slabs_) {
             for (T*& f : sl.field) free_field(f);
@@ -427,7 +429,7 @@ public:
         }
         SF_HIP(hipGetLastError());
         if (P_ > 1) {
-            for (Slab& sl : slabs_) SF_HIP(hipEventRecord(sl.boundary_done, sl.cs));
+            for (Slab& sl : slabs_) ev_record(sl, &Slab::boundary_done, sl.cs);
             const int fs[1] = {x};
             exchange<1>(fs);
         }
@@ -891,14 +893,96 @@ private:
     //   hs: halo exchange of B's planes, concurrent with I
     // so a pair costs max(I, B + exchange) instead of B + max(I, exchange). Whole-field operators run on cs after
     // join(), which makes cs wait for the last B and the last halo.
+    // ---- schedule trace (SF_TRACE_SCHEDULE=<file>) -------------------------------------------------------------
+    // Every launch, exchange and stream-ordering call of the decomposed step is appended to <file> as one JSON line:
+    //   {"t":"ctx", ...}                                   context geometry (first line of a context)
+    //   {"t":"op","name":..,"slab":g,"stream":"cs|bs|hs","acc":[["r"|"w",buffer,lo,hi],...]}   plane ranges [lo,hi)
+    //   {"t":"rec","slab":g,"stream":..,"ev":..}           hipEventRecord
+    //   {"t":"wait","slab":g,"stream":..,"ev":..,"evslab":h}   hipStreamWaitEvent (on the event's latest record)
+    //   {"t":"xchg","seq":n,"fields":[..],"G":G}           one halo exchange (sequence number: the same on every rank)
+    // Reads carry the stencil reach of the kernel (an S-sweep launch reads x on S planes either side). tests/
+    // schedule_check.py rebuilds the happens-before relation (stream order + event edges) and asserts that no two
+    // accesses to overlapping planes of one buffer, one of them a write, are unordered — the write-after-read race of
+    // round 2 (DESIGN §4 log) is such a pair. ",inject=trap" after the file name re-introduces that bug (growth S_j
+    // instead of max(S_j, S_{j-1})) so the checker can be shown to catch it; results may then be wrong by design.
+    struct Acc {
+        const void* buf;
+        bool write;
+        int lo, hi;
+    };
+    using AccFn = std::function<void(Slab&, int, int, std::vector<Acc>&)>;
+    void trace_open() {
+        const char* t = std::getenv("SF_TRACE_SCHEDULE");
+        if (!t || !*t) return;
+        std::string path(t);
+        const size_t c = path.find(',');
+        if (c != std::string::npos) {
+            inject_trap_bug_ = path.substr(c + 1) == "inject=trap";
+            path.resize(c);
+        }
+        trace_ = std::fopen(path.c_str(), "a");
+        if (!trace_) throw Failure{SF_ERR_INVALID, "SF_TRACE_SCHEDULE: cannot open " + path};
+        std::fprintf(trace_, "{\"t\":\"ctx\",\"N\":%d,\"P\":%d,\"L\":%d,\"rank\":%d,\"G\":%d,\"nzl\":%d,\"np\":%d,\"trap\":%d,"
+                             "\"hs_is_bs\":%d,\"inject\":%d}\n",
+                     N_, P_, L_, rank_, G_, nzl_, nplanes_, trap_m_, slabs_[0].hs == slabs_[0].bs ? 1 : 0,
+                     inject_trap_bug_ ? 1 : 0);
+    }
+    const char* sname(const Slab& sl, hipStream_t st) const { return st == sl.cs ? "cs" : (st == sl.bs ? "bs" : "hs"); }
+    static const char* ename(hipEvent_t Slab::*e) {
+        return e == &Slab::cs_mark ? "cs_mark" : (e == &Slab::boundary_done ? "boundary" : "halo");
+    }
+    int buf_id(const void* p) {
+        auto it = buf_ids_.find(p);
+        if (it == buf_ids_.end()) it = buf_ids_.emplace(p, (int)buf_ids_.size()).first;
+        return it->second;
+    }
+    void ev_record(Slab& sl, hipEvent_t Slab::*e, hipStream_t st) {
+        SF_HIP(hipEventRecord(sl.*e, st));
+        if (trace_)
+            std::fprintf(trace_, "{\"t\":\"rec\",\"slab\":%d,\"stream\":\"%s\",\"ev\":\"%s\"}\n", sl.gid, sname(sl, st), ename(e));
+    }
+    void st_wait(Slab& wsl, hipStream_t st, Slab& esl, hipEvent_t Slab::*e) {
+        SF_HIP(hipStreamWaitEvent(st, esl.*e, 0));
+        if (trace_)
+            std::fprintf(trace_, "{\"t\":\"wait\",\"slab\":%d,\"stream\":\"%s\",\"ev\":\"%s\",\"evslab\":%d}\n", wsl.gid,
+                         sname(wsl, st), ename(e), esl.gid);
+    }
+    void tr_op(const char* name, const Slab& sl, hipStream_t st, const std::vector<Acc>& acc) {
+        if (!trace_) return;
+        std::fprintf(trace_, "{\"t\":\"op\",\"name\":\"%s\",\"slab\":%d,\"stream\":\"%s\",\"acc\":[", name, sl.gid, sname(sl, st));
+        bool first = true;
+        for (const Acc& a : acc) {
+            const int lo = std::max(a.lo, 0), hi = std::min(a.hi, nplanes_);
+            if (lo >= hi) continue;
+            std::fprintf(trace_, "%s[\"%s\",%d,%d,%d]", first ? "" : ",", a.write ? "w" : "r", buf_id(a.buf), lo, hi);
+            first = false;
+        }
+        std::fprintf(trace_, "]}\n");
+        std::fflush(trace_);
+    }
+    // whole-field operator on the compute stream
+    void tr_whole(const char* name, const Slab& sl, std::initializer_list<const void*> reads,
+                  std::initializer_list<const void*> writes) {
+        if (!trace_) return;
+        std::vector<Acc> acc;
+        for (const void* r : reads) acc.push_back({r, false, 0, nplanes_});
+        for (const void* w : writes) acc.push_back({w, true, 0, nplanes_});
+        tr_op(name, sl, sl.cs, acc);
+    }
+    // planes [kb, ke) written by a launch, widened by the physical shell plane a wall slab's launch also writes
+    void wr_range(const Slab& sl, int kb, int ke, int& lo, int& hi) const {
+        lo = (sl.geom.wall_lo && kb == G_) ? kb - 1 : kb;
+        hi = (sl.geom.wall_hi && ke == G_ + nzl_) ? ke + 1 : ke;
+    }
+
     void join() {
         if (P_ == 1 || !pending_join_) return;
         for (int s = 0; s < L_; ++s) {
             Slab& sl = slabs_[s];
-            SF_HIP(hipStreamWaitEvent(sl.cs, sl.boundary_done, 0));
-            SF_HIP(hipStreamWaitEvent(sl.cs, sl.halo_done, 0));
-            if (s > 0) SF_HIP(hipStreamWaitEvent(sl.cs, slabs_[s - 1].halo_done, 0));
-            if (s < L_ - 1) SF_HIP(hipStreamWaitEvent(sl.cs, slabs_[s + 1].halo_done, 0));
+            st_wait(sl, sl.cs, sl, &Slab::boundary_done);
+            st_wait(sl, sl.cs, sl, &Slab::halo_done);
+            if (s > 0) st_wait(sl, sl.cs, slabs_[s - 1], &Slab::halo_done);
+            if (s < L_ - 1) st_wait(sl, sl.cs, slabs_[s + 1], &Slab::halo_done);
         }
         pending_join_ = false;
     }
@@ -909,9 +993,18 @@ private:
         // the boundary launch (whose completion the halo stream waits for), not out of the interior launch
         depth = std::max(depth, G_);
         const int kb = G_, ke = G_ + nzl_;
+        // trace: the accesses of this operator over the plane ranges one launch covers
+        auto emit = [&](Slab& sl, hipStream_t st, int a0, int a1, int b0 = 0, int b1 = 0) {
+            if (!trace_ || !acc_fn_) return;
+            std::vector<Acc> acc;
+            acc_fn_(sl, a0, a1, acc);
+            if (b1 > b0) acc_fn_(sl, b0, b1, acc);
+            tr_op(acc_name_, sl, st, acc);
+        };
         if (P_ == 1) {
             slabs_[0].cur = slabs_[0].cs;
             launch(slabs_[0], kb, ke);
+            emit(slabs_[0], slabs_[0].cs, kb, ke);
             SF_HIP(hipGetLastError());
             return;
         }
@@ -928,30 +1021,36 @@ private:
                 sl.cur = sl.cs;
                 if (nzl_ <= 2 * depth) {
                     launch(sl, kb, ke);
-                    SF_HIP(hipEventRecord(sl.boundary_done, sl.cs));
+                    emit(sl, sl.cs, kb, ke);
+                    ev_record(sl, &Slab::boundary_done, sl.cs);
                 } else {
                     launch(sl, kb, kb + depth);
+                    emit(sl, sl.cs, kb, kb + depth);
                     launch(sl, ke - depth, ke);
-                    SF_HIP(hipEventRecord(sl.boundary_done, sl.cs));
+                    emit(sl, sl.cs, ke - depth, ke);
+                    ev_record(sl, &Slab::boundary_done, sl.cs);
                     launch(sl, kb + depth, ke - depth);
+                    emit(sl, sl.cs, kb + depth, ke - depth);
                 }
                 continue;
             }
             // I of this operator reads what the previous B wrote (unless B has grown, see above); B reads everything
             // issued on cs so far
-            if (extra == 0) SF_HIP(hipStreamWaitEvent(sl.cs, sl.boundary_done, 0));
-            SF_HIP(hipEventRecord(sl.cs_mark, sl.cs));
-            SF_HIP(hipStreamWaitEvent(sl.bs, sl.cs_mark, 0));
+            if (extra == 0) st_wait(sl, sl.cs, sl, &Slab::boundary_done);
+            ev_record(sl, &Slab::cs_mark, sl.cs);
+            st_wait(sl, sl.bs, sl, &Slab::cs_mark);
             // ONE launch over the first and the last `depth` interior planes (split plane range)
             sl.cur = sl.bs;
             split_ = depth;
             gap_ = nzl_ - 2 * depth;
             launch(sl, kb, kb + 2 * depth);
+            emit(sl, sl.bs, kb, kb + depth, ke - depth, ke);
             split_ = INT_MAX;
             gap_ = 0;
-            SF_HIP(hipEventRecord(sl.boundary_done, sl.bs));
+            ev_record(sl, &Slab::boundary_done, sl.bs);
             sl.cur = sl.cs;
             launch(sl, kb + depth, ke - depth);
+            emit(sl, sl.cs, kb + depth, ke - depth);
         }
         SF_HIP(hipGetLastError());
     }
@@ -960,6 +1059,33 @@ private:
     template <class F, class... Args>
     void launch_k(Slab& sl, F kernel, dim3 nblocks, unsigned nthreads, Args... args) {
         hipLaunchKernelGGL(kernel, nblocks, dim3(nthreads), 0, sl.cur, args...);
+    }
+
+    // trace of one slab's share of a halo exchange on stream `st`: its low / high ghost planes are written from the last
+    // / first interior planes of `lo` / `hi` (the neighbouring slab of this process; with a neighbour in another
+    // process — or the loopback stand-in — the planes READ are this slab's own outgoing ones)
+    template <int NF>
+    void tr_halo(const char* name, Slab& sl, hipStream_t st, const int (&fields)[NF], Slab* lo, Slab* hi, bool lo_remote,
+                 bool hi_remote) {
+        if (!trace_) return;
+        std::vector<Acc> acc;
+        for (int f = 0; f < NF; ++f) {
+            const T* mine = sl.field[fields[f]];
+            if (lo) acc.push_back({lo->field[fields[f]], false, nzl_, nzl_ + G_});
+            if (lo_remote) acc.push_back({mine, false, G_, 2 * G_});
+            if (lo || lo_remote) acc.push_back({mine, true, 0, G_});
+            if (hi) acc.push_back({hi->field[fields[f]], false, G_, 2 * G_});
+            if (hi_remote) acc.push_back({mine, false, nzl_, nzl_ + G_});
+            if (hi || hi_remote) acc.push_back({mine, true, G_ + nzl_, 2 * G_ + nzl_});
+        }
+        tr_op(name, sl, st, acc);
+    }
+    template <int NF>
+    void tr_xchg(const int (&fields)[NF]) {
+        if (!trace_) return;
+        std::fprintf(trace_, "{\"t\":\"xchg\",\"seq\":%ld,\"G\":%d,\"fields\":[", xchg_seq_, G_);
+        for (int f = 0; f < NF; ++f) std::fprintf(trace_, "%s%d", f ? "," : "", fields[f]);
+        std::fprintf(trace_, "]}\n");
     }
 
     // Halo exchange of NF fields: first / last interior plane -> neighbour's ghost plane.
@@ -972,17 +1098,19 @@ private:
         const size_t bytes = gcount * sizeof(T);
         const size_t send_lo = (size_t)G_ * plane_, send_hi = (size_t)nzl_ * plane_;
         const size_t recv_lo = 0, recv_hi = (size_t)(G_ + nzl_) * plane_;
+        tr_xchg<NF>(fields);
+        ++xchg_seq_;
         if (rccl_self_) {
             exchange_rccl_self<NF>(fields, gcount, send_lo, send_hi, recv_lo, recv_hi);
             return;
         }
         for (int s = 0; s < L_; ++s) {
             Slab& sl = slabs_[s];
-            SF_HIP(hipStreamWaitEvent(sl.hs, sl.boundary_done, 0));
+            st_wait(sl, sl.hs, sl, &Slab::boundary_done);
             const bool has_lo = sl.gid > 0, has_hi = sl.gid < P_ - 1;
             const bool lo_local = has_lo && s > 0, hi_local = has_hi && s < L_ - 1;
-            if (lo_local) SF_HIP(hipStreamWaitEvent(sl.hs, slabs_[s - 1].boundary_done, 0));
-            if (hi_local) SF_HIP(hipStreamWaitEvent(sl.hs, slabs_[s + 1].boundary_done, 0));
+            if (lo_local) st_wait(sl, sl.hs, slabs_[s - 1], &Slab::boundary_done);
+            if (hi_local) st_wait(sl, sl.hs, slabs_[s + 1], &Slab::boundary_done);
             // pull from neighbours that live in this process: one copy kernel for all fields and both sides
             if (lo_local || hi_local) {
                 sfk::HaloCopyArgs H;
@@ -1002,6 +1130,8 @@ private:
                 const unsigned gx = (unsigned)std::max(1L, std::min((H.n16 + 255) / 256, 512L));
                 hipLaunchKernelGGL(sfk::halo_copy_kernel, dim3(gx, H.nseg), dim3(256), 0, sl.hs, H);
                 SF_HIP(hipGetLastError());
+                tr_halo<NF>("halo_pull", sl, sl.hs, fields, lo_local ? &slabs_[s - 1] : nullptr,
+                            hi_local ? &slabs_[s + 1] : nullptr, false, false);
             }
             // neighbours in other processes: grouped send/recv over RCCL (xGMI point-to-point)
             const bool lo_remote = has_lo && !lo_local, hi_remote = has_hi && !hi_local;
@@ -1024,6 +1154,7 @@ private:
                 const unsigned gx = (unsigned)std::max(1L, std::min((H.n16 + 255) / 256, 512L));
                 hipLaunchKernelGGL(sfk::halo_copy_kernel, dim3(gx, H.nseg), dim3(256), 0, sl.hs, H);
                 SF_HIP(hipGetLastError());
+                tr_halo<NF>("halo_loopback", sl, sl.hs, fields, nullptr, nullptr, lo_remote, hi_remote);
             } else if (lo_remote || hi_remote) {
                 const ncclDataType_t dt = sizeof(T) == 4 ? ncclFloat : ncclDouble;
                 SF_NCCL(ncclGroupStart());
@@ -1040,17 +1171,18 @@ private:
                 }
                 SF_NCCL(ncclGroupEnd());
                 ++rccl_groups_;
+                tr_halo<NF>("halo_rccl", sl, sl.hs, fields, nullptr, nullptr, lo_remote, hi_remote);
             }
-            SF_HIP(hipEventRecord(sl.halo_done, sl.hs));
+            ev_record(sl, &Slab::halo_done, sl.hs);
         }
         // consumers: the next boundary launch reads my ghosts, and neighbours that pulled from my planes must be
         // done before I overwrite them two sweeps later. The compute stream only waits when it runs a
         // whole-field operator (join()).
         for (int s = 0; s < L_; ++s) {
             Slab& sl = slabs_[s];
-            SF_HIP(hipStreamWaitEvent(sl.bs, sl.halo_done, 0));
-            if (s > 0) SF_HIP(hipStreamWaitEvent(sl.bs, slabs_[s - 1].halo_done, 0));
-            if (s < L_ - 1) SF_HIP(hipStreamWaitEvent(sl.bs, slabs_[s + 1].halo_done, 0));
+            st_wait(sl, sl.bs, sl, &Slab::halo_done);
+            if (s > 0) st_wait(sl, sl.bs, slabs_[s - 1], &Slab::halo_done);
+            if (s < L_ - 1) st_wait(sl, sl.bs, slabs_[s + 1], &Slab::halo_done);
         }
         pending_join_ = true;
     }
@@ -1068,9 +1200,9 @@ private:
         const ncclDataType_t dt = sizeof(T) == 4 ? ncclFloat : ncclDouble;
         for (int s = 0; s < L_; ++s) {
             Slab& sl = slabs_[s];
-            SF_HIP(hipStreamWaitEvent(sl.hs, sl.boundary_done, 0));
-            if (s > 0) SF_HIP(hipStreamWaitEvent(sl.hs, slabs_[s - 1].boundary_done, 0));
-            if (s < L_ - 1) SF_HIP(hipStreamWaitEvent(sl.hs, slabs_[s + 1].boundary_done, 0));
+            st_wait(sl, sl.hs, sl, &Slab::boundary_done);
+            if (s > 0) st_wait(sl, sl.hs, slabs_[s - 1], &Slab::boundary_done);
+            if (s < L_ - 1) st_wait(sl, sl.hs, slabs_[s + 1], &Slab::boundary_done);
         }
         SF_NCCL(ncclGroupStart());
         for (int s = 0; s + 1 < L_; ++s) {
@@ -1089,12 +1221,15 @@ private:
         }
         SF_NCCL(ncclGroupEnd());
         ++rccl_groups_;
-        for (int s = 0; s < L_; ++s) SF_HIP(hipEventRecord(slabs_[s].halo_done, slabs_[s].hs));
+        for (int s = 0; s < L_; ++s)
+            tr_halo<NF>("halo_rccl_self", slabs_[s], slabs_[s].hs, fields, s > 0 ? &slabs_[s - 1] : nullptr,
+                        s < L_ - 1 ? &slabs_[s + 1] : nullptr, false, false);
+        for (int s = 0; s < L_; ++s) ev_record(slabs_[s], &Slab::halo_done, slabs_[s].hs);
         for (int s = 0; s < L_; ++s) {
             Slab& sl = slabs_[s];
-            SF_HIP(hipStreamWaitEvent(sl.bs, sl.halo_done, 0));
-            if (s > 0) SF_HIP(hipStreamWaitEvent(sl.bs, slabs_[s - 1].halo_done, 0));
-            if (s < L_ - 1) SF_HIP(hipStreamWaitEvent(sl.bs, slabs_[s + 1].halo_done, 0));
+            st_wait(sl, sl.bs, sl, &Slab::halo_done);
+            if (s > 0) st_wait(sl, sl.bs, slabs_[s - 1], &Slab::halo_done);
+            if (s < L_ - 1) st_wait(sl, sl.bs, slabs_[s + 1], &Slab::halo_done);
         }
         pending_join_ = true;
     }
@@ -1112,6 +1247,7 @@ private:
             A.dt = dt_;
             A.nvec = nvec;
             hipLaunchKernelGGL((sfk::add_source_kernel<T, NF>), dim3((unsigned)ceil_div(nvec, 256L)), dim3(256), 0, sl.cs, A);
+            for (int f = 0; f < NF; ++f) tr_whole("add_source", sl, {A.x[f], A.s[f]}, {A.x[f]});
         }
         SF_HIP(hipGetLastError());
         // ghosts of x and s were current, so the ghosts of the result are current: no exchange
@@ -1131,6 +1267,7 @@ private:
             A.dt = dt_;
             A.nvec = nvec;
             hipLaunchKernelGGL((sfk::add_source_bound_kernel<T, NF>), dim3((unsigned)ceil_div(nvec, 256L)), dim3(256), 0, sl.cs, A);
+            for (int f = 0; f < NF; ++f) tr_whole("add_source_bound", sl, {A.x[f], A.src[f]}, {A.x[f], A.s_copy[f]});
         }
         SF_HIP(hipGetLastError());
     }
@@ -1517,7 +1654,8 @@ private:
             int extra = 0;
             {
                 // does this launch continue the trapezoid block?
-                const int d = dprev + std::max(step, sprev);  // where its interior launch would start
+                // (inject_trap_bug_: SF_TRACE_SCHEDULE's ",inject=trap" — the round-2 race, for the checker's own test)
+                const int d = dprev + (inject_trap_bug_ ? step : std::max(step, sprev));  // where its interior launch would start
                 bool cont = pair && P_ > 1 && G_ >= 2 && trap_m_ > 1 && tj > 0 && tj < trap_m_ && d >= depth0 &&
                             nzl_ > 2 * d + 2;
                 if (cont && step >= 3 && sweeps_in_launch(it, K, continued, d - depth0) != step) cont = false;
@@ -1530,6 +1668,18 @@ private:
             const bool triple = step >= 3;  // three or four sweeps: the marching kernel
             trap_extra_ = extra;
             ++tj;
+            if (trace_) {
+                acc_name_ = step == 4 ? "jacobi4" : (step == 3 ? "jacobi3" : (step == 2 ? "jacobi2" : "jacobi1"));
+                acc_fn_ = [&, step](Slab& sl, int a, int b, std::vector<Acc>& acc) {
+                    int lo, hi;
+                    wr_range(sl, a, b, lo, hi);
+                    for (int f = 0; f < NF; ++f) {
+                        if (!x_is_zero_) acc.push_back({sl.field[x[f]], false, a - step, b + step});
+                        acc.push_back({sl.field[x0[f]], false, a - (step - 1), b + (step - 1)});
+                        acc.push_back({sl.scratch[f], true, lo, hi});
+                    }
+                };
+            }
             for_planes([&](Slab& sl, int kb, int ke) {
                 sfk::JacobiArgs<T, NF> A;
                 for (int f = 0; f < NF; ++f) {
@@ -1549,6 +1699,7 @@ private:
                 else
                     launch_jacobi<NF>(sl, A, kb, ke, it == 0 && !continued, it + step == K);
             }, step == 2 ? pair_depth() : step, true);
+            acc_fn_ = nullptr;
             // the new iterate becomes the field; the old buffer becomes scratch
             for (Slab& sl : slabs_)
                 for (int f = 0; f < NF; ++f) std::swap(sl.field[x[f]], sl.scratch[f]);
@@ -1581,6 +1732,17 @@ private:
             R.nvec = (long)(G_ - 1) * plane_ / W;
             hipLaunchKernelGGL((sfk::rhs_planes_kernel<T, NF>), dim3((unsigned)ceil_div(R.nvec, 256L), 2), dim3(256), 0,
                                two ? sl.bs : sl.cs, R);
+            if (trace_) {
+                std::vector<Acc> acc;
+                for (int f = 0; f < NF; ++f)
+                    for (int side = 0; side < 2; ++side) {
+                        const int lo = side ? G_ + nzl_ : 1, hi = lo + G_ - 1;
+                        acc.push_back({sl.field[x[f]], false, lo, hi});
+                        acc.push_back({sl.field[src[f]], false, lo, hi});
+                        acc.push_back({sl.field[x0[f]], true, lo, hi});
+                    }
+                tr_op("rhs_ghost", sl, two ? sl.bs : sl.cs, acc);
+            }
         }
         SF_HIP(hipGetLastError());
     }
@@ -1618,6 +1780,20 @@ private:
                 ensure(sl, x0[f]);
                 ensure(sl, src[f]);
             }
+        const int sreach = sk_first_ok(K) ? 4 : 2;  // sweeps of the first pass = its reach in planes
+        if (trace_) {
+            acc_name_ = "jacobi_src";
+            acc_fn_ = [&, sreach](Slab& sl, int a, int b, std::vector<Acc>& acc) {
+                int lo, hi;
+                wr_range(sl, a, b, lo, hi);
+                for (int f = 0; f < NF; ++f) {
+                    acc.push_back({sl.field[src[f]], false, a - sreach, b + sreach});
+                    acc.push_back({sl.field[x[f]], false, a - (sreach - 1), b + (sreach - 1)});
+                    acc.push_back({sl.scratch[f], true, lo, hi});
+                    acc.push_back({sl.field[x0[f]], true, a, b});
+                }
+            };
+        }
         if (sk_first_ok(K)) {
             // the same pass as four sweeps of the marching kernel (undecomposed grid): rhs formed per plane as it
             // arrives, stored for the later launches
@@ -1635,6 +1811,7 @@ private:
                 A.dt = dt_;
                 launch_sk_first<NF>(sl, A, kb, ke, 2);
             }, 4, true);
+            acc_fn_ = nullptr;
             rhs_on_ghost_planes<NF>(x, x0, src, 4);
             for (Slab& sl : slabs_)
                 for (int f = 0; f < NF; ++f) std::swap(sl.field[x[f]], sl.scratch[f]);
@@ -1656,6 +1833,7 @@ private:
             A.dt = dt_;
             launch_jacobi2<NF, true>(sl, A, kb, ke, true, K == 2);
         }, pair_depth(), true);
+        acc_fn_ = nullptr;
         rhs_on_ghost_planes<NF>(x, x0, src, pair_depth());
         for (Slab& sl : slabs_)
             for (int f = 0; f < NF; ++f) std::swap(sl.field[x[f]], sl.scratch[f]);
@@ -1674,6 +1852,20 @@ private:
             ensure(sl, u);
             ensure(sl, v);
             ensure(sl, w);
+        }
+        if (trace_) {
+            acc_name_ = "advect";
+            acc_fn_ = [&](Slab& sl, int a, int b_, std::vector<Acc>& acc) {
+                int lo, hi;
+                wr_range(sl, a, b_, lo, hi);
+                for (int f = 0; f < NF; ++f) {
+                    acc.push_back({sl.field[d0[f]], false, a - 1, b_ + 1});
+                    acc.push_back({sl.field[d[f]], true, lo, hi});
+                }
+                acc.push_back({sl.field[u], false, a, b_});
+                acc.push_back({sl.field[v], false, a, b_});
+                acc.push_back({sl.field[w], false, a, b_});
+            };
         }
         for_planes([&](Slab& sl, int kb, int ke) {
             sfk::AdvectArgs<T, NF> A;
@@ -1707,6 +1899,7 @@ private:
             } else
                 hipLaunchKernelGGL((sfk::advect_kernel<T, NF>), dim3(nblocks), block, 0, sl.cur, sl.geom, A, kb, ke, m);
         }, 1, true, /*interior_reads_ghosts=*/true);  // a long back-trace may reach a ghost plane from any plane
+        acc_fn_ = nullptr;
         exchange<NF>(d);
     }
 
@@ -1730,7 +1923,21 @@ private:
         if (!implicit_zero) join();
         for (Slab& sl : slabs_) {
             ensure(sl, p);
-            if (!implicit_zero) SF_HIP(hipMemsetAsync(sl.field[p], 0, (size_t)field_elems_ * sizeof(T), sl.cs));
+            if (!implicit_zero) {
+                SF_HIP(hipMemsetAsync(sl.field[p], 0, (size_t)field_elems_ * sizeof(T), sl.cs));
+                tr_whole("zero_p", sl, {}, {sl.field[p]});
+            }
+        }
+        if (trace_) {
+            acc_name_ = "project_div";
+            acc_fn_ = [&](Slab& sl, int a, int b_, std::vector<Acc>& acc) {
+                int lo, hi;
+                wr_range(sl, a, b_, lo, hi);
+                acc.push_back({sl.field[u], false, a, b_});
+                acc.push_back({sl.field[v], false, a, b_});
+                acc.push_back({sl.field[w], false, a - 1, b_ + 1});
+                acc.push_back({sl.field[div], true, lo, hi});
+            };
         }
         for_planes([&](Slab& sl, int kb, int ke) {
             dim3 block;
@@ -1738,6 +1945,7 @@ private:
             const sfk::TileMap m = flat_map(ke - kb, block, nblocks);
             hipLaunchKernelGGL((sfk::project_div_kernel<T>), dim3(nblocks), block, 0, sl.cur, sl.geom, args(sl), kb, ke, m);
         });
+        acc_fn_ = nullptr;
         // div's ghost planes are exchanged although a single sweep reads div at cell centres only: the fused
         // sweep pair evaluates its first sweep on the first ghost plane and needs x0 = div there, and div is left
         // in the v0 slot, where the caller may use it as the next step's source / initial guess (all G planes).
@@ -1746,12 +1954,25 @@ private:
         exchange<1>(dv);
         const int ps[1] = {p}, b0[1] = {0};
         op_lin_solve<1>(ps, dv, b0, T(1), T(6), K_, implicit_zero);
+        if (trace_) {
+            acc_name_ = "project_sub";
+            acc_fn_ = [&](Slab& sl, int a, int b_, std::vector<Acc>& acc) {
+                int lo, hi;
+                wr_range(sl, a, b_, lo, hi);
+                acc.push_back({sl.field[p], false, a - 1, b_ + 1});
+                for (int q : {u, v, w}) {
+                    acc.push_back({sl.field[q], false, a, b_});
+                    acc.push_back({sl.field[q], true, lo, hi});
+                }
+            };
+        }
         for_planes([&](Slab& sl, int kb, int ke) {
             dim3 block;
             unsigned nblocks;
             const sfk::TileMap m = flat_map(ke - kb, block, nblocks);
             hipLaunchKernelGGL((sfk::project_sub_kernel<T>), dim3(nblocks), block, 0, sl.cur, sl.geom, args(sl), kb, ke, m);
         });
+        acc_fn_ = nullptr;
         const int uvw[3] = {u, v, w};
         exchange<3>(uvw);
     }
@@ -1776,6 +1997,12 @@ private:
     bool sk_first_ = true;
     long plane_ = 0, field_elems_ = 0, pad_front_ = 0, pad_back_ = 0;
     std::vector<Slab> slabs_;
+    FILE* trace_ = nullptr;  // SF_TRACE_SCHEDULE
+    bool inject_trap_bug_ = false;
+    std::map<const void*, int> buf_ids_;
+    AccFn acc_fn_;           // accesses of the operator being issued through for_planes (trace only)
+    const char* acc_name_ = "op";
+    long xchg_seq_ = 0;
     ncclComm_t comm_ = nullptr;
     bool loopback_ = false, rccl_self_ = false;
     long rccl_groups_ = 0;  // RCCL send/recv groups issued so far (sf_schedule_info: proof the transport ran)
