@@ -56,5 +56,4 @@ def run(tag, N, P, K, trap, flags, env, inject):
 if __name__ == "__main__":
     for c in CASES:
         run(*c, inject=False)
-    for c in CASES[:2]:
-        run(*c, inject=True)
+    run(*CASES[0], inject=True)  # K = 11: a three-sweep launch continues the trapezoid block of a four-sweep one

@@ -37,13 +37,14 @@ def test_slab_schedule_over_gloo(tmp_path, world, N, K, dtype):
 # SF_MARCH_MINCELLS_K does, so that small grids take the deep schedules (G = 3, 4; S = 3, 4).
 PROD_CASES = [
     # world, N, K, dtype, mincells_k, bound     -> expected ghost depth
-    (2, 48, 7, "f32", 10, "0"),    # nzl 24: G = 3 (interior 18 >= 12), passes 2 + 3 + 2
+    (2, 48, 7, "f32", 10, "0"),    # nzl 24: G = 4 (interior 16 >= 12), passes 4 + 3
     (2, 64, 11, "f32", 10, "1"),   # nzl 32: G = 4, first pass 4 (folded source) + 4 + 3
     (2, 64, 20, "f32", 10, "0"),   # G = 4, 4 + 4 x 4
-    (4, 96, 9, "f32", 10, "1"),    # nzl 24: G = 3, bound sources through the pair kernel (2) + 3 + 4 -> 2 + 3 + 2 + 2
+    (4, 96, 9, "f32", 10, "1"),    # nzl 24: G = 4, bound sources: first pass 4 (folded) + 3 + 2
     (4, 32, 6, "f64", 6000, "1"),  # default thresholds: G = 2, pairs only
-    (2, 40, 5, "f64", 10, "0"),    # nzl 20: G = 3, odd K: 2 + 3
+    (2, 40, 5, "f64", 10, "0"),    # nzl 20: G = 4 (interior 12), odd K below the first-pass threshold: 2 + 3
     (2, 12, 4, "f32", 6000, "1"),  # thin slabs (nzl 6): G = 2
+    (2, 36, 8, "f32", 10, "1"),    # nzl 18: G = 3 (interior 12; four ghost planes would leave 10), pair + 3 + 3
 ]
 
 
@@ -55,6 +56,23 @@ def test_production_schedule_over_gloo(tmp_path, world, N, K, dtype, mincells_k,
            "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
            os.path.join(HERE, "dist_worker.py"), str(out), str(N), str(K), dtype, "prod", str(mincells_k), bound]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert out.read_text() == "OK"
+
+
+@pytest.mark.parametrize("world,N,K,trace", [(2, 96, 11, "head_n96_p2_k11_trap8.jsonl"), (2, 128, 7, "head_n128_p2_k7_trap5.jsonl"),
+                                             (4, 64, 6, "head_n64_p4_k6_trap5.jsonl")])
+def test_emulator_exchange_sequence_equals_the_device_trace(tmp_path, world, N, K, trace):
+    """Every rank of the gloo emulation issues the exchanges libsfgpu.so recorded on the MI355X for the same (N, P, K)
+    (tests/golden/schedule/, SF_TRACE_SCHEDULE with SF_MARCH_MINCELLS_K=100): same number, order, ghost depth and field
+    slots — and the emulated result still equals the undecomposed oracle."""
+    out = tmp_path / "result.txt"
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+           os.path.join(HERE, "dist_worker.py"), str(out), str(N), str(K), "f32", "prod", "100", "1",
+           os.path.join(HERE, "golden", "schedule", trace)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert out.read_text() == "OK"
 
@@ -109,7 +127,8 @@ def test_emulator_notices_schedule_defects():
     assert ok and log[0] == (0, 4, (0,)) and len(log) == 3 * 3 + 2 * (1 + 3 + 1) + 1 + 3 + 1
     assert not _emulate(64, 2, 11, True, "rhs_ghost")[0]
     assert not _emulate(64, 2, 11, True, "shallow_exchange")[0]
-    assert not _emulate(48, 2, 7, False, "shallow_exchange")[0]
+    assert not _emulate(64, 2, 11, False, "shallow_exchange")[0]
+    assert _emulate(48, 2, 7, False, "shallow_exchange")[0]  # passes 4 + 3 on four ghost planes: the last one is never read
 
 
 def test_partition_arithmetic():
