@@ -1088,12 +1088,30 @@ struct SkWall {
     int jtN;      // tile row of j = N in the last j-block (rows beyond it do not exist)
 };
 
+// Diagnostic build only (tools/sk_probe.hip, -DSF_SK_STAMP): s_memtime stamps at five points of every march step,
+// summed per wave: where do the cycles of a step go? No stamp executes in libsfgpu.so.
+#ifdef SF_SK_STAMP
+__device__ unsigned long long* g_sk_stamp = nullptr;  // [workgroup][wave][8]
+#define SF_SK_T(q)                                                \
+    do {                                                          \
+        const long long t_ = __builtin_amdgcn_s_memtime();        \
+        fx.st[q] += (unsigned long long)(t_ - fx.tlast);          \
+        fx.tlast = t_;                                            \
+    } while (0)
+#else
+#define SF_SK_T(q) do { } while (0)
+#endif
+
 template <class T, int TJ>
 struct SkFirst {
     T xs[4][TJ];         // ring of the row-end shell cells of x (modes 1, 2)
     T* __restrict__ prhs;  // mode 2: plane kk of x0out (clamped like px)
     T dt;
     int k0, k1;
+#ifdef SF_SK_STAMP
+    unsigned long long st[8];
+    long long tlast;
+#endif
 };
 
 template <class T, int WL, bool NT, int S, int TJ, int NW, int PH, int NACT, bool WALLS, bool ISH, bool ROWEND, int FIRST>
@@ -1220,6 +1238,7 @@ __device__ __forceinline__ void jsk_step(const Geom& g, SkShared<T, WL, S, TJ, N
 #pragma unroll
         for (int l = 1; l <= NACT; ++l) read_halo(l);
     }
+    SF_SK_T(0);  // requests issued, halo reads issued
     __builtin_amdgcn_sched_barrier(0);
     // (3) levels 1 .. NACT
 #pragma unroll
@@ -1395,6 +1414,8 @@ __device__ __forceinline__ void jsk_step(const Geom& g, SkShared<T, WL, S, TJ, N
                 }
             }
         }
+        if (l == 1) SF_SK_T(1);  // level 1 (waits for x(kk+1), x0(kk))
+        if (l == NACT && NACT > 1) SF_SK_T(2);  // levels 2 .. NACT, stores
         if constexpr (XSH) {
             if (l == 1) {
                 // level 1 was the last reader of x(kk-1): shift, and request x(kk+2) into the slot that fell free
@@ -1424,8 +1445,13 @@ __device__ __forceinline__ void jsk_step(const Geom& g, SkShared<T, WL, S, TJ, N
             sh.edge[WB][l][wave][1][lane] = yr[l - 1][sw][TJ - 1];
         }
     if (NACT == S) pout += g.plane;
+    SF_SK_T(3);  // edge rows published
     // (5) one barrier per step (LDS only: the global requests stay in flight across it)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    SF_SK_T(4);  // barrier
+#ifdef SF_SK_STAMP
+    fx.st[5] += 1;
+#endif
 }
 
 template <class T, int WL, bool NT, int S, int TJ, int NW, bool WALLS, bool ISH, bool ROWEND, int FIRST>
@@ -1458,6 +1484,10 @@ __device__ __forceinline__ void jsk_march(const Geom& g, SkShared<T, WL, S, TJ, 
     fx.k0 = k0;
     fx.k1 = k1;
     fx.prhs = x0out + (long)(kk > kmax ? kmax : (kk < 0 ? 0 : kk)) * g.plane;
+#ifdef SF_SK_STAMP
+    for (int q = 0; q < 8; ++q) fx.st[q] = 0;
+    const long long t_begin = __builtin_amdgcn_s_memtime();
+#endif
     {
         // planes kk-1, kk, kk+1 of x in ring slots 3, 0, 1; x0(kk) in slot 0
         const __amdgpu_buffer_rsrc_t pa = plane_of_k(x, kk - 1), pb = plane_of_k(x, kk), pc = plane_of_k(x, kk + 1);
@@ -1501,6 +1531,9 @@ __device__ __forceinline__ void jsk_march(const Geom& g, SkShared<T, WL, S, TJ, 
                                                                           ps0, pout, kk, a, inv, sx, sy, sz, jw,       \
                                                                           wave, lane, first_vec, last_vec, fx)
     const int kend = k1 + S - 2;  // last step
+#ifdef SF_SK_STAMP
+    fx.tlast = __builtin_amdgcn_s_memtime();
+#endif
     SF_SK_STEP(0, 1);
     ++kk;
     SF_SK_STEP(1, 1);
@@ -1552,6 +1585,13 @@ __device__ __forceinline__ void jsk_march(const Geom& g, SkShared<T, WL, S, TJ, 
         }
     }
 #undef SF_SK_STEP
+#ifdef SF_SK_STAMP
+    fx.st[6] = (unsigned long long)(__builtin_amdgcn_s_memtime() - t_begin);
+    if (g_sk_stamp && lane == 0) {
+        const long wg = (long)blockIdx.x + (long)gridDim.x * ((long)blockIdx.y + (long)gridDim.y * blockIdx.z);
+        for (int q = 0; q < 8; ++q) g_sk_stamp[(wg * NW + wave) * 8 + q] = fx.st[q];
+    }
+#endif
 }
 
 #ifndef SF_SK_WAVES

@@ -12,11 +12,14 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
 enum Mode { ADD_IND, PK_ADD_IND, PK_MUL_IND, ADD_DEP, PK_ADD_DEP, DPP_ADD_IND, CNDMASK_IND, FMA_IND, PK_FMA_IND, MOV_IND,
-            PK_ADD_DEP2, ADD_DEP2, NMODES };
+            PK_ADD_DEP2, ADD_DEP2, CNDMASK_E64, BFI_IND, AND_OR_IND, MUL_IND, PK_ADD_NOP, MAX_IND, NMODES };
 static const char* NAMES[NMODES] = {"v_add_f32 x16 independent", "v_pk_add_f32 x16 independent", "v_pk_mul_f32 x16 independent",
                                     "v_add_f32 dependent chain", "v_pk_add_f32 dependent chain", "v_add_f32_dpp wave_shr x16 independent",
                                     "v_cndmask_b32 x16 independent", "v_fma_f32 x16 independent", "v_pk_fma_f32 x16 independent",
-                                    "v_mov_b32 x16 independent", "v_pk_add_f32 two interleaved chains", "v_add_f32 two interleaved chains"};
+                                    "v_mov_b32 x16 independent", "v_pk_add_f32 two interleaved chains", "v_add_f32 two interleaved chains",
+                                    "v_cndmask_b32_e64 (SGPR-pair mask) x16 independent", "v_bfi_b32 x16 independent",
+                                    "v_and_or_b32 x16 independent", "v_mul_f32 x16 independent",
+                                    "v_pk_add_f32 + s_nop 0 x16 independent", "v_max_f32 x16 independent"};
 
 template <int MODE>
 __global__ void probe(long long* out, float* sink, int iters, float seed) {
@@ -24,6 +27,7 @@ __global__ void probe(long long* out, float* sink, int iters, float seed) {
 #pragma unroll
     for (int q = 0; q < 16; ++q) a[q] = f2{seed + q, seed - q};
     const f2 b = f2{seed * 0.5f, seed * 0.25f};
+    const unsigned long long msk = __builtin_amdgcn_read_exec() ^ (unsigned long long)(iters & 1);  // wave-uniform mask
     __syncthreads();
     const long long t0 = __builtin_amdgcn_s_memtime();
     for (int it = 0; it < iters; ++it) {
@@ -45,6 +49,12 @@ __global__ void probe(long long* out, float* sink, int iters, float seed) {
                 if (MODE == FMA_IND) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(a[q].x) : "v"(b.x));
                 if (MODE == PK_FMA_IND) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(a[q]) : "v"(b));
                 if (MODE == MOV_IND) asm volatile("v_mov_b32 %0, %1" : "+v"(a[q].x) : "v"(b.x));
+                if (MODE == CNDMASK_E64) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(a[q].x) : "v"(b.x), "s"(msk));
+                if (MODE == BFI_IND) asm volatile("v_bfi_b32 %0, %1, %2, %0" : "+v"(a[q].x) : "v"(b.y), "v"(b.x));
+                if (MODE == AND_OR_IND) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(a[q].x) : "v"(b.y), "v"(b.x));
+                if (MODE == MUL_IND) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[q].x) : "v"(b.x));
+                if (MODE == PK_ADD_NOP) asm volatile("v_pk_add_f32 %0, %0, %1\n\ts_nop 0" : "+v"(a[q]) : "v"(b));
+                if (MODE == MAX_IND) asm volatile("v_max_f32 %0, %0, %1" : "+v"(a[q].x) : "v"(b.x));
             }
         }
     }
@@ -85,6 +95,7 @@ int main() {
     printf("s_memtime ticks per instruction as seen by ONE wave (median over waves), one workgroup per CU\n");
     printf("%-42s | 1 w/SIMD | 2 waves/SIMD          | 4 waves/SIMD\n", "instruction stream");
     row<ADD_IND>(); row<PK_ADD_IND>(); row<PK_MUL_IND>(); row<FMA_IND>(); row<PK_FMA_IND>(); row<MOV_IND>();
-    row<DPP_ADD_IND>(); row<CNDMASK_IND>(); row<ADD_DEP>(); row<PK_ADD_DEP>(); row<ADD_DEP2>(); row<PK_ADD_DEP2>();
+    row<DPP_ADD_IND>(); row<CNDMASK_IND>(); row<CNDMASK_E64>(); row<BFI_IND>(); row<AND_OR_IND>(); row<MUL_IND>();
+    row<MAX_IND>(); row<PK_ADD_NOP>(); row<ADD_DEP>(); row<PK_ADD_DEP>(); row<ADD_DEP2>(); row<PK_ADD_DEP2>();
     return 0;
 }
