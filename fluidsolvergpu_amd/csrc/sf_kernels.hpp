@@ -1088,10 +1088,11 @@ struct SkWall {
     int jtN;      // tile row of j = N in the last j-block (rows beyond it do not exist)
 };
 
-// Diagnostic build only (tools/sk_probe.hip, -DSF_SK_STAMP): s_memtime stamps at five points of every march step,
-// summed per wave: where do the cycles of a step go? No stamp executes in libsfgpu.so.
+// Diagnostic build only (tools/sk_probe.hip, -DSF_SK_STAMP): s_memtime stamps at eight points of every march step,
+// summed per wave: where do the cycles of a step go? No stamp executes in libsfgpu.so. (A stamp orders memory
+// operations only: hipcc moves vector arithmetic across it, so the split BETWEEN the levels is approximate.)
 #ifdef SF_SK_STAMP
-__device__ unsigned long long* g_sk_stamp = nullptr;  // [workgroup][wave][8]
+__device__ unsigned long long* g_sk_stamp = nullptr;  // [workgroup][wave][10]
 #define SF_SK_T(q)                                                \
     do {                                                          \
         const long long t_ = __builtin_amdgcn_s_memtime();        \
@@ -1109,7 +1110,7 @@ struct SkFirst {
     T dt;
     int k0, k1;
 #ifdef SF_SK_STAMP
-    unsigned long long st[8];
+    unsigned long long st[10];
     long long tlast;
 #endif
 };
@@ -1415,7 +1416,9 @@ __device__ __forceinline__ void jsk_step(const Geom& g, SkShared<T, WL, S, TJ, N
             }
         }
         if (l == 1) SF_SK_T(1);  // level 1 (waits for x(kk+1), x0(kk))
-        if (l == NACT && NACT > 1) SF_SK_T(2);  // levels 2 .. NACT, stores
+        if (l == 2) SF_SK_T(3);
+        if (l == 3) SF_SK_T(4);
+        if (l == 4) SF_SK_T(5);  // level 4 and its stores
         if constexpr (XSH) {
             if (l == 1) {
                 // level 1 was the last reader of x(kk-1): shift, and request x(kk+2) into the slot that fell free
@@ -1427,6 +1430,7 @@ __device__ __forceinline__ void jsk_step(const Geom& g, SkShared<T, WL, S, TJ, N
                     xr[1][r] = xr[2][r];
                 }
                 request_x();
+                SF_SK_T(2);  // shift + request of x(kk+2)
             }
         }
     }
@@ -1445,12 +1449,12 @@ __device__ __forceinline__ void jsk_step(const Geom& g, SkShared<T, WL, S, TJ, N
             sh.edge[WB][l][wave][1][lane] = yr[l - 1][sw][TJ - 1];
         }
     if (NACT == S) pout += g.plane;
-    SF_SK_T(3);  // edge rows published
+    SF_SK_T(6);  // edge rows published
     // (5) one barrier per step (LDS only: the global requests stay in flight across it)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    SF_SK_T(4);  // barrier
+    SF_SK_T(7);  // barrier
 #ifdef SF_SK_STAMP
-    fx.st[5] += 1;
+    fx.st[8] += 1;
 #endif
 }
 
@@ -1485,7 +1489,7 @@ __device__ __forceinline__ void jsk_march(const Geom& g, SkShared<T, WL, S, TJ, 
     fx.k1 = k1;
     fx.prhs = x0out + (long)(kk > kmax ? kmax : (kk < 0 ? 0 : kk)) * g.plane;
 #ifdef SF_SK_STAMP
-    for (int q = 0; q < 8; ++q) fx.st[q] = 0;
+    for (int q = 0; q < 10; ++q) fx.st[q] = 0;
     const long long t_begin = __builtin_amdgcn_s_memtime();
 #endif
     {
@@ -1586,10 +1590,10 @@ __device__ __forceinline__ void jsk_march(const Geom& g, SkShared<T, WL, S, TJ, 
     }
 #undef SF_SK_STEP
 #ifdef SF_SK_STAMP
-    fx.st[6] = (unsigned long long)(__builtin_amdgcn_s_memtime() - t_begin);
+    fx.st[9] = (unsigned long long)(__builtin_amdgcn_s_memtime() - t_begin);
     if (g_sk_stamp && lane == 0) {
         const long wg = (long)blockIdx.x + (long)gridDim.x * ((long)blockIdx.y + (long)gridDim.y * blockIdx.z);
-        for (int q = 0; q < 8; ++q) g_sk_stamp[(wg * NW + wave) * 8 + q] = fx.st[q];
+        for (int q = 0; q < 10; ++q) g_sk_stamp[(wg * NW + wave) * 10 + q] = fx.st[q];
     }
 #endif
 }

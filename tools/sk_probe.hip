@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
@@ -60,9 +61,11 @@ void run(int N, const char* what, int gx, int gy, int gz_override) {
     dim3 grid(gx > 0 ? gx : 8, gy > 0 ? gy : m.band, gz_override > 0 ? gz_override : nchunk);
     const long nwg = (long)grid.x * grid.y * grid.z;
     unsigned long long* d_st;
-    CK(hipMalloc(&d_st, nwg * NW * 8 * sizeof(unsigned long long)));
-    CK(hipMemset(d_st, 0, nwg * NW * 8 * sizeof(unsigned long long)));
+    CK(hipMalloc(&d_st, nwg * NW * 10 * sizeof(unsigned long long)));
+    CK(hipMemset(d_st, 0, nwg * NW * 10 * sizeof(unsigned long long)));
+#ifdef SF_SK_STAMP
     CK(hipMemcpyToSymbol(HIP_SYMBOL(sfk::g_sk_stamp), &d_st, sizeof(d_st)));
+#endif
     sfk::JacobiArgs<T, 1> A{};
     A.x[0] = x + front; A.x0[0] = x0 + front; A.xn[0] = xn + front; A.b[0] = 0; A.a = 0.3f; A.inv = 1.0f / 2.8f;
     A.x0out[0] = xn + front; A.dt = 0.1f;
@@ -78,25 +81,47 @@ void run(int N, const char* what, int gx, int gy, int gz_override) {
         CK(hipEventElapsedTime(&ms, e0, e1));
         best = std::min(best, ms);
     }
-    std::vector<unsigned long long> st(nwg * NW * 8);
+    unsigned long long sum_bits = 0;
+    if (gz_override == 0 && gx == 0) {  // whole grid: checksum of the output (variants must agree bit for bit)
+        std::vector<T> h((size_t)(front + elems + back));
+        CK(hipMemcpy(h.data(), xn, bytes, hipMemcpyDeviceToHost));
+        for (size_t q = 0; q < h.size(); ++q) {
+            unsigned u;
+            memcpy(&u, &h[q], 4);
+            sum_bits = (sum_bits ^ u) * 1099511628211ull;
+        }
+    }
+    std::vector<unsigned long long> st(nwg * NW * 10);
     CK(hipMemcpy(st.data(), d_st, st.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    double sum[8] = {}, nw = 0;
+    double sum[10] = {}, nw = 0;
     for (long w = 0; w < nwg * NW; ++w) {
-        if (st[w * 8 + 5] == 0) continue;  // workgroups beyond ncb return at once
-        for (int q = 0; q < 8; ++q) sum[q] += (double)st[w * 8 + q];
+        if (st[w * 10 + 8] == 0) continue;  // workgroups beyond ncb return at once / build without stamps
+        for (int q = 0; q < 10; ++q) sum[q] += (double)st[w * 10 + q];
         nw += 1;
     }
-    const double steps = sum[5] / nw;
-    printf("%-34s N=%d NT=%d grid %ux%ux%u (%ld wg, kc=%d): %8.1f us | steps/wave %5.1f | cycles per step: request %5.0f  level1 %5.0f  "
-           "levels2-4 %5.0f  publish %5.0f  barrier %5.0f  = %6.0f  (whole march %7.0f/step)\n",
-           what, N, (int)NT, grid.x, grid.y, grid.z, nwg, m.kc, best * 1e3, steps, sum[0] / sum[5], sum[1] / sum[5], sum[2] / sum[5],
-           sum[3] / sum[5], sum[4] / sum[5], (sum[0] + sum[1] + sum[2] + sum[3] + sum[4]) / sum[5], sum[6] / sum[5]);
+    printf("%-34s N=%d NT=%d grid %ux%ux%u (%ld wg, kc=%d): %8.1f us", what, N, (int)NT, grid.x, grid.y, grid.z, nwg, m.kc, best * 1e3);
+    if (nw > 0) {
+        const double n = sum[8];
+        printf(" | steps/wave %5.1f | cycles/step: x0 request+halo read %4.0f  level1 %4.0f  x request %4.0f  level2 %4.0f  level3 %4.0f  "
+               "level4+stores %4.0f  publish %4.0f  sync %4.0f = %5.0f", n / nw, sum[0] / n, sum[1] / n, sum[2] / n, sum[3] / n, sum[4] / n,
+               sum[5] / n, sum[6] / n, sum[7] / n, (sum[0] + sum[1] + sum[2] + sum[3] + sum[4] + sum[5] + sum[6] + sum[7]) / n);
+    }
+    printf("\n");
+    if (sum_bits) printf("    output checksum %016llx\n", sum_bits);
+    if (nwg == 1 && nw > 0)  // the lone workgroup, wave by wave (waves w and w + 4 share a SIMD)
+        for (int w = 0; w < NW; ++w) {
+            const unsigned long long* q = &st[w * 10];
+            const double n = (double)q[8];
+            printf("      wave %d: x0 request+halo read %4.0f  level1 %4.0f  x request %4.0f  level2 %4.0f  level3 %4.0f  level4+stores %4.0f  "
+                   "publish %4.0f  sync %4.0f\n", w, q[0] / n, q[1] / n, q[2] / n, q[3] / n, q[4] / n, q[5] / n, q[6] / n, q[7] / n);
+        }
     CK(hipFree(d_st)); CK(hipFree(x)); CK(hipFree(x0)); CK(hipFree(xn));
 }
 
 int main(int argc, char** argv) {
     const int sizes[2] = {256, 512};
     for (int N : sizes) {
+        if (argc > 1 && N != atoi(argv[1])) continue;
         run<false>(N, "whole grid", 0, 0, 0);
         if (N == 512) run<true>(N, "whole grid", 0, 0, 0);
         run<false>(N, "one chunk layer (8 x band x 1)", 0, 0, 1);
