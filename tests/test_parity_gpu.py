@@ -136,6 +136,10 @@ def test_lin_solve_rows_that_straddle_waves(N, K, b, dtype, march_mode):
     """Row widths that are not a power of two, and rows wider than two waves (up to 258 vectors here): the fused
     kernel's overlapped mapping packs the (row pair, vector) items of a plane pair into 60-lane windows, so rows
     start and end anywhere inside a wave."""
+    if march_mode == "marching" and N >= 300:
+        pytest.skip("above the marching kernel's size threshold 'auto' already is the marching schedule")
+    if N >= 500 and dtype == np.float64:
+        pytest.skip("512^3 fp64 against the oracle: tests/test_full_size_gpu.py")
     f = rand_fields(N, dtype, 50)
     a, c = 0.21, 1 + 6 * 0.21
     with make(N, dtype) as fs:
@@ -163,16 +167,22 @@ def advect_form(request, monkeypatch):
     """advect has three forms: four cells per thread with per-cell gathers of (i0, i0+1) pairs; one cell per lane with
     the i0+1 samples taken from the neighbour lane; one cell per lane with own pair loads. By default the second / third
     serve the three velocity components in fp32 / fp64 and the first everything else. SF_ADVECT_ROW = 0 / 2 / 3 force
-    one form for every call, so each sees every size, dtype and boundary mode of these tests."""
+    one form for every call, so each sees every size, dtype and boundary mode of these tests. (A fourth form — two
+    cells per lane, aligned pair gathers, 32-bit buffer offsets — was built in round 3, bit-identical and not faster:
+    profiles/r03_advect_two_cells_experiment.txt.)"""
     if request.param != "default":
         monkeypatch.setenv("SF_ADVECT_ROW", {"gather": "0", "row": "2", "pairs": "3"}[request.param])
     return request.param
 
 
+ADVECT_CASES = [(N, b) for N in (1, 2, 5, 8, 16, 31) for b in (0, 1, 2, 3)] + [(34, 1), (70, 2), (130, 3), (130, 0), (256, 0),
+                                                                                 (256, 1)]
+
+
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "f64"])
-@pytest.mark.parametrize("b", [0, 1, 2, 3])
-@pytest.mark.parametrize("N", [1, 2, 5, 8, 16, 31, 34, 70, 130])
+@pytest.mark.parametrize("N,b", ADVECT_CASES)
 def test_advect(N, b, dtype, advect_form):
+
     # velocities large enough to hit the clamp at both ends and every fractional position
     f = rand_fields(N, dtype, 6, scale=1.0)
     with make(N, dtype) as fs:
@@ -209,8 +219,10 @@ def test_advect_smooth_flow(N, b, dtype, advect_form):
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "f64"])
 @pytest.mark.parametrize("mode", ["near", "mixed"])
-@pytest.mark.parametrize("N,b", [(1, 0), (3, 1), (8, 2), (13, 3), (32, 1), (64, 0), (100, 2)])
-def test_advect_short_and_long_backtraces(N, b, mode, dtype):
+@pytest.mark.parametrize("N,b", [(1, 0), (3, 1), (8, 2), (13, 3), (32, 1), (64, 0), (100, 2), (130, 3)])
+def test_advect_short_and_long_backtraces(N, b, mode, dtype, advect_form):
+    if advect_form in ("row", "pairs") and N < 32:
+        pytest.skip("the one-cell-per-lane forms on tiny grids: test_advect")
     """Back-traces shorter than one cell ('near'), and 'mixed': a few long back-traces (several cells, clamped at the
     walls) scattered into the field. Either way the result must equal the oracle."""
     rng = np.random.RandomState(60 + N)
@@ -706,10 +718,10 @@ def test_invalid_arguments_are_rejected():
 
 # ---- size-independent properties at BASELINE.json's sizes (the oracle is too slow there) ---------
 
-@pytest.mark.parametrize("N,dtype", [(256, np.float32), (512, np.float32), (512, np.float64)],
-                         ids=["256-f32", "512-f32", "512-f64"])
+@pytest.mark.parametrize("N,dtype", [(256, np.float32), (512, np.float64)], ids=["256-f32", "512-f64"])
 def test_large_properties(N, dtype):
-    """configs[1], configs[2] and configs[4] of BASELINE.json (grid and precision; the oracle is too slow there)."""
+    """Size-independent properties at configs[1] and configs[4] of BASELINE.json (grid and precision). The bit-exact
+    comparisons with the oracle at these sizes, and at configs[2] (512^3 fp32), are in tests/test_full_size_gpu.py."""
     K = 20
     rng = np.random.RandomState(13)
     with make(N, dtype, K=K) as fs:
