@@ -34,6 +34,8 @@
 #include <sstream>
 #include <string>
 #include <thread>
+#include <ctime>
+#include <sys/stat.h>
 #include <unistd.h>
 #include <vector>
 
@@ -78,6 +80,12 @@ static std::string nccl_id_path() {
     return path;
 }
 
+// Start of this process (seconds since the epoch), from /proc: files older than it cannot belong to this launch.
+static time_t process_start_time() {
+    struct stat st;
+    return stat("/proc/self", &st) == 0 ? st.st_ctime : time(nullptr);
+}
+
 static void share_nccl_id(const Options& o, unsigned char* id) {
     const std::string path = nccl_id_path();
     if (o.rank == 0) {
@@ -94,12 +102,18 @@ static void share_nccl_id(const Options& o, unsigned char* id) {
             exit(1);
         }
     } else {
+        // With SF_NCCL_ID_FILE the name is NOT unique per launch: a file older than this process was left by an
+        // earlier (crashed) run — rank 0 of this run has not published yet — and is not taken.
+        const time_t born = process_start_time();
         for (int tries = 0; tries < 1200; ++tries) {  // up to 120 s
-            FILE* f = fopen(path.c_str(), "rb");
-            if (f) {
-                const size_t n = fread(id, 1, SF_NCCL_ID_BYTES, f);
-                fclose(f);
-                if (n == SF_NCCL_ID_BYTES) return;
+            struct stat st;
+            if (stat(path.c_str(), &st) == 0 && st.st_mtime + 1 >= born) {
+                FILE* f = fopen(path.c_str(), "rb");
+                if (f) {
+                    const size_t n = fread(id, 1, SF_NCCL_ID_BYTES, f);
+                    fclose(f);
+                    if (n == SF_NCCL_ID_BYTES) return;
+                }
             }
             usleep(100000);
         }
@@ -113,6 +127,7 @@ static Options parse(int argc, char** argv) {
     o.rank = env_int("RANK", 0);
     o.world = env_int("WORLD_SIZE", 1);
     o.local_rank = env_int("LOCAL_RANK", 0);
+    bool rank_or_world_given = false;
     for (int a = 1; a < argc; ++a) {
         const std::string s = argv[a];
         auto next = [&]() -> const char* {
@@ -138,12 +153,18 @@ static Options parse(int argc, char** argv) {
         // rehearsal of ONE rank's share on a one-GPU box: the geometry, buffers, launches and frame file of rank
         // --rank of --world, halo messages replaced by device-local copies (SF_FLAG_LOOPBACK_HALO), no communicator
         else if (s == "--loopback") o.loopback = true;
-        else if (s == "--rank") o.rank = atoi(next());
-        else if (s == "--world") o.world = atoi(next());
+        else if (s == "--rank") { o.rank = atoi(next()); rank_or_world_given = true; }
+        else if (s == "--world") { o.world = atoi(next()); rank_or_world_given = true; }
         else {
             fprintf(stderr, "unknown option %s\n", s.c_str());
             exit(2);
         }
+    }
+    // --rank / --world override the launcher's environment only to rehearse one rank's share with local copies: without
+    // --loopback a real communicator would wait 120 s for an id nobody publishes
+    if (rank_or_world_given && !o.loopback) {
+        fprintf(stderr, "--rank / --world need --loopback (ranks of a real run come from RANK / WORLD_SIZE)\n");
+        exit(2);
     }
     // frames go to <out>/: create it (the reference writes into the working directory, which always exists)
     if (o.every > 0) {

@@ -196,7 +196,7 @@ public:
     // Which trapezoid depth suits THIS machine's halo latency (see the comment at trap_m_)? Times a 20-sweep
     // lin_solve on the (still zero) density slots for 0, 2 and 5 pairs per block and keeps the fastest, preferring
     // the shallower one unless the deeper is 3 % faster. Every rank runs the same sequence of exchanges whatever it
-    // picks (the depth only moves planes between this rank's own two launches), so ranks may differ in their choice.
+    // picks (the depth only moves planes between this rank's own two launches).
     void tune_schedule() {
         if (!(G_ >= 2 && can_fuse2()) || nzl_ <= 2 * (G_ + 2) + 2) return;
         const int x[1] = {SF_DENS}, x0[1] = {SF_DENS0}, b0[1] = {0};
@@ -209,6 +209,30 @@ public:
                 SF_HIP(hipStreamSynchronize(sl.hs));
             }
         };
+        // The ranks measure TOGETHER: a one-word all-reduce lines them up before the clock starts (a rank that starts
+        // its solves early would time its neighbours' set-up), and the time that counts is the slowest rank's — the
+        // step runs at that pace — so every rank sees the same numbers and takes the same decision. (Round 2 timed each
+        // rank by itself.) d_sync[0]: barrier word, d_sync[1]: the time in microseconds.
+        long long* d_sync = nullptr;
+        if (comm_) {
+            SF_HIP(hipMalloc(&d_sync, 2 * sizeof(long long)));
+            SF_HIP(hipMemset(d_sync, 0, 2 * sizeof(long long)));
+            SF_HIP(hipDeviceSynchronize());
+        }
+        auto line_up = [&] {
+            if (!comm_) return;
+            SF_NCCL(ncclAllReduce(d_sync, d_sync, 1, ncclInt64, ncclSum, comm_, slabs_[0].cs));
+            SF_HIP(hipStreamSynchronize(slabs_[0].cs));
+        };
+        auto slowest = [&](double t) -> double {
+            if (!comm_) return t;
+            long long us = (long long)(t * 1e6);
+            SF_HIP(hipMemcpy(d_sync + 1, &us, sizeof us, hipMemcpyHostToDevice));
+            SF_NCCL(ncclAllReduce(d_sync + 1, d_sync + 1, 1, ncclInt64, ncclMax, comm_, slabs_[0].cs));
+            SF_HIP(hipStreamSynchronize(slabs_[0].cs));
+            SF_HIP(hipMemcpy(&us, d_sync + 1, sizeof us, hipMemcpyDeviceToHost));
+            return (double)us * 1e-6;
+        };
         const int cand[3] = {0, 2, 5};
         double best = 0;
         int best_m = 0;
@@ -216,10 +240,11 @@ public:
             trap_m_ = cand[q];
             op_lin_solve<1>(x, x0, b0, a, c, 10);  // warm-up (first use of the communicator, caches)
             drain();
+            line_up();
             const auto t0 = std::chrono::steady_clock::now();
             for (int r = 0; r < 3; ++r) op_lin_solve<1>(x, x0, b0, a, c, 20);
             drain();
-            const double t = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            const double t = slowest(std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
             if (q == 0 || t < 0.97 * best) {
                 best = t;
                 best_m = cand[q];
@@ -238,17 +263,18 @@ public:
                 split_fields_ = q == 0 ? 1 : 0;
                 op_lin_solve<3>(vel, vel0, b123, a, c, 4);
                 drain();
+                line_up();
                 const auto t0 = std::chrono::steady_clock::now();
                 for (int r = 0; r < 2; ++r) op_lin_solve<3>(vel, vel0, b123, a, c, 20);
                 drain();
-                const double t = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                const double t = slowest(std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
                 if (q == 0)
                     t_split = t;
                 else if (!(t < 0.97 * t_split))
                     split_fields_ = 1;
             }
-            // unlike the trapezoid depth this changes the sequence of exchanges, so the ranks must agree: the batched
-            // form is used only if every rank prefers it
+            // unlike the trapezoid depth this changes the sequence of exchanges, so the ranks must agree: they now compare
+            // the same (slowest-rank) times, and the vote below stays as the guard that they really did
             if (comm_) {
                 int* d_vote = nullptr;
                 int vote = split_fields_ == 0 ? 1 : 0, sum = 0;
@@ -262,6 +288,7 @@ public:
             }
             tuned_split_ = split_fields_;
         }
+        if (d_sync) SF_HIP(hipFree(d_sync));
     }
 
     ~Solver() override {

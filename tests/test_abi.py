@@ -71,3 +71,11 @@ def test_status_strings():
     assert solver.lib.sf_status_string(0) == b"SF_OK"
     assert solver.lib.sf_status_string(4) == b"SF_ERR_HALO_EXCEEDED"
     assert "gfx950" in solver.version()
+
+
+def test_driver_rejects_rank_override_without_loopback():
+    """`sf_driver --rank r --world w` rehearses one rank's share with local copies (--loopback); without it a real
+    communicator would wait for an id nobody publishes: refused at once, before anything touches the device."""
+    exe = os.path.join(ROOT, "fluidsolvergpu_amd", "sf_driver")
+    out = subprocess.run([exe, "--rank", "1", "--world", "2", "--every", "0"], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 2 and "--loopback" in out.stderr
