@@ -3,7 +3,7 @@
 
 torch.distributed is used for the CONTROL plane only (rendezvous, shipping the ncclUniqueId, barriers,
 gathering results for output, max-over-ranks timing). The data plane — ghost-plane exchange per Jacobi
-sweep — is RCCL send/recv inside libsfgpu.so (csrc/sf_api.hip, exchange()). Everything here also runs
+sweep — is RCCL send/recv inside libsfgpu.so (csrc/sf_solver.hpp, exchange()). Everything here also runs
 on the gloo backend with no GPU, which is how tests/test_dist_gloo.py covers the N > 1 host path.
 
 The reference's counterpart is its two-device scaffolding (solver-unidyn.cu:79-96 split of the cell

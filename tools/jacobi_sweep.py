@@ -1,5 +1,5 @@
 """tools/jacobi_sweep.py — time the lin_solve sweep (HIP events) for the current build.
-usage: python tools/jacobi_sweep.py [N ...]; environment knobs are read by libsfgpu.so (SF_KCHUNK, ...)."""
+usage: python tools/jacobi_sweep.py [N ...]; environment switches are read by libsfgpu.so."""
 import os
 import sys
 
