@@ -1903,6 +1903,11 @@ struct ProjectArgs {
     T* p;
     T* div;
     T c_div, c_grad;
+    // The i = 0 / N+1 cells of u (project_div) / p (project_sub) are not read from memory but mirrored from the row's
+    // end cells — exactly what set_bnd(1, u) / set_bnd(0, p) would have stored there: -u[1], -u[N] / p[1], p[N]. Set
+    // when the solve that produced the field left its i-shell unwritten (Solver::vel_step_body: those 2 N^2 x planes
+    // isolated four-byte writes per field are partial writes to HBM and cost a 512^3 last pass 18 %).
+    int mirror_u, mirror_p;
 };
 
 template <class T>
@@ -1914,14 +1919,17 @@ __global__ void __launch_bounds__(256) project_div_kernel(Geom g, ProjectArgs<T>
     if (!flat_cell<W>(g, m, kb, ke, i0, j, kl, nv)) return;
     const long q = row0(g, j, kl) + i0;
     const V uc = ldv(A.u + q);
-    const T um = A.u[q - 1], up = A.u[q + W];
+    T um = A.u[q - 1];
+    const T up = A.u[q + W];
+    if (A.mirror_u && i0 == 1) um = T(-1) * uc[0];
     const V vm = ldv(A.v + q - g.px), vp = ldv(A.v + q + g.px);
     const V wm = ldv(A.w + q - g.plane), wp = ldv(A.w + q + g.plane);
     T out[W];
 #pragma unroll
     for (int e = 0; e < W; ++e) {
         const T left = (e == 0) ? um : uc[e - 1];
-        const T right = (e == W - 1) ? up : uc[e + 1];
+        T right = (e == W - 1) ? up : uc[e + 1];
+        if (A.mirror_u && i0 + e == g.N) right = T(-1) * uc[e];  // (a ragged last vector holds cell N+1 itself)
         out[e] = A.c_div * (((right - left) + (vp[e] - vm[e])) + (wp[e] - wm[e]));
     }
     store_cells<T, W>(A.div, q - i0, i0, out, nv);
@@ -1939,7 +1947,9 @@ __global__ void __launch_bounds__(256) project_sub_kernel(Geom g, ProjectArgs<T>
     const long q = row0(g, j, kl) + i0;
     const T* __restrict__ p = A.p;
     const V pc = ldv(p + q);
-    const T pm = p[q - 1], pp = p[q + W];
+    T pm = p[q - 1];
+    const T pp = p[q + W];
+    if (A.mirror_p && i0 == 1) pm = T(1) * pc[0];
     const V pjm = ldv(p + q - g.px), pjp = ldv(p + q + g.px);
     const V pkm = ldv(p + q - g.plane), pkp = ldv(p + q + g.plane);
     const V uc = ldv(A.u + q), vc = ldv(A.v + q), wc = ldv(A.w + q);
@@ -1947,7 +1957,8 @@ __global__ void __launch_bounds__(256) project_sub_kernel(Geom g, ProjectArgs<T>
 #pragma unroll
     for (int e = 0; e < W; ++e) {
         const T left = (e == 0) ? pm : pc[e - 1];
-        const T right = (e == W - 1) ? pp : pc[e + 1];
+        T right = (e == W - 1) ? pp : pc[e + 1];
+        if (A.mirror_p && i0 + e == g.N) right = T(1) * pc[e];
         ou[e] = uc[e] - A.c_grad * (right - left);
         ov[e] = vc[e] - A.c_grad * (pjp[e] - pjm[e]);
         ow[e] = wc[e] - A.c_grad * (pkp[e] - pkm[e]);

@@ -167,6 +167,7 @@ public:
         }
         nt_mode_ = env_int("SF_NT", 2);  // non-temporal stores: 0 never, 1 always, 2 beyond the Infinity Cache
         ishell_skip_ = env_int("SF_ISHELL", 1) != 0;
+        dead_ishell_opt_ = env_int("SF_ISHELL", 1) == 1;
         fuse2_ = env_int("SF_FUSE2", 1) != 0;  // 0 single sweeps, 1 fused sweeps (default)
         advect_row_ = env_int("SF_ADVECT_ROW", 1);
         zero_skip_ = env_int("SF_ZERO_SKIP", 1) != 0;
@@ -599,6 +600,13 @@ public:
     void vel_step_body() {
         const int vel[3] = {SF_U, SF_V, SF_W}, vel0[3] = {SF_U0, SF_V0, SF_W0}, b123[3] = {1, 2, 3};
         const T a = diffusion_a(visc_);
+        // Nobody reads the i-shell of the diffused velocity: project_div reads v and w at interior i only and mirrors u's
+        // (b = 1), project_sub then rewrites all three shells from the corrected interior. Likewise the pressure of this
+        // FIRST projection: its slot is overwritten by advect before anything else looks at it. Their solves therefore
+        // leave the i-shell unwritten (no partial writes to HBM: a 512^3 last pass takes 441 instead of 520 us). K_ = 0
+        // runs no sweep: the fields keep their caller-written shells and are read from memory as before.
+        const bool dead = ishell_skip_ && K_ >= 1 && dead_ishell_opt_;
+        dead_ishell_ = dead;
         if (bound_[0] >= 0 && bound_[1] >= 0 && bound_[2] >= 0) {
             const int src[3] = {bound_[0], bound_[1], bound_[2]};
             op_diffuse_src<3>(vel, vel0, b123, src, a, T(1) + T(6) * a, K_);
@@ -611,7 +619,8 @@ public:
             swap_slots(SF_W0, SF_W);
             op_lin_solve<3>(vel, vel0, b123, a, T(1) + T(6) * a, K_);
         }
-        op_project(SF_U, SF_V, SF_W, SF_U0, SF_V0);
+        dead_ishell_ = false;
+        op_project(SF_U, SF_V, SF_W, SF_U0, SF_V0, dead, dead);
         swap_slots(SF_U0, SF_U);
         swap_slots(SF_V0, SF_V);
         swap_slots(SF_W0, SF_W);
@@ -1693,6 +1702,8 @@ private:
                 sprev = step;
             }
             const bool triple = step >= 3;  // three or four sweeps: the marching kernel
+            // the pass that writes the i-shell: the last one, unless nothing will read that shell (dead_ishell_)
+            const bool last = it + step == K && !dead_ishell_;
             trap_extra_ = extra;
             ++tj;
             if (trace_) {
@@ -1720,11 +1731,11 @@ private:
                 if (it == 0 && !continued && step == 4)
                     launch_sk_first<NF>(sl, A, kb, ke, x_zero ? 3 : 1);
                 else if (triple)
-                    launch_jacobi_s<NF>(sl, A, kb, ke, it + step == K, step);
+                    launch_jacobi_s<NF>(sl, A, kb, ke, last, step);
                 else if (pair)
-                    launch_jacobi2<NF>(sl, A, kb, ke, it == 0 && !continued, it + step == K);
+                    launch_jacobi2<NF>(sl, A, kb, ke, it == 0 && !continued, last);
                 else
-                    launch_jacobi<NF>(sl, A, kb, ke, it == 0 && !continued, it + step == K);
+                    launch_jacobi<NF>(sl, A, kb, ke, it == 0 && !continued, last);
             }, step == 2 ? pair_depth() : step, true);
             acc_fn_ = nullptr;
             // the new iterate becomes the field; the old buffer becomes scratch
@@ -1858,7 +1869,7 @@ private:
             A.a = a;
             A.inv = inv;
             A.dt = dt_;
-            launch_jacobi2<NF, true>(sl, A, kb, ke, true, K == 2);
+            launch_jacobi2<NF, true>(sl, A, kb, ke, true, K == 2 && !dead_ishell_);
         }, pair_depth(), true);
         acc_fn_ = nullptr;
         rhs_on_ghost_planes<NF>(x, x0, src, pair_depth());
@@ -1930,7 +1941,12 @@ private:
         exchange<NF>(d);
     }
 
-    void op_project(int u, int v, int w, int p, int div) {
+    // mirror_u: u's i-shell was left unwritten by the solve before (b = 1: mirrored in project_div); dead_p: nothing reads
+    // p after this projection (its slot is overwritten before anyone looks), so the solve leaves p's i-shell unwritten
+    // and project_sub mirrors it. Both false for the public sf_project().
+    void op_project(int u, int v, int w, int p, int div, bool mirror_u = false, bool dead_p = false) {
+        mirror_u = mirror_u && ishell_skip_;
+        dead_p = dead_p && ishell_skip_ && K_ >= 1;
         const T Nf = (T)N_;
         const T h = T(1) / Nf;
         auto args = [&](Slab& sl) {
@@ -1942,6 +1958,8 @@ private:
             A.div = ensure(sl, div);
             A.c_div = T(-0.5) * h;
             A.c_grad = T(0.5) * Nf;
+            A.mirror_u = mirror_u ? 1 : 0;
+            A.mirror_p = dead_p ? 1 : 0;
             return A;
         };
         // p = 0: when the first two sweeps are fused the kernel treats x as literal zeros and p is never read,
@@ -1980,7 +1998,9 @@ private:
         const int dv[1] = {div};
         exchange<1>(dv);
         const int ps[1] = {p}, b0[1] = {0};
+        dead_ishell_ = dead_p;
         op_lin_solve<1>(ps, dv, b0, T(1), T(6), K_, implicit_zero);
+        dead_ishell_ = false;
         if (trace_) {
             acc_name_ = "project_sub";
             acc_fn_ = [&](Slab& sl, int a, int b_, std::vector<Acc>& acc) {
@@ -2016,6 +2036,8 @@ private:
     int num_cu_ = 256;
     int nzl_ = 0, lead_ = 0, px_ = 0, nplanes_ = 0, nt_mode_ = 2;
     int advect_row_ = 1;  // 0 gather form always, 1 one cell per lane for the three velocity components, 2 / 3 always
+    bool dead_ishell_ = false;      // the solve being issued may leave its result's i-shell unwritten
+    bool dead_ishell_opt_ = true;   // SF_ISHELL=2 switches the dead-shell elision off (1: on, 0: every sweep writes it)
     bool ishell_skip_ = true, zero_skip_ = true, x_is_zero_ = false, fuse_src_ = true;
     bool fuse2_ = true;
     int march_k_ = 1, march_min_planes_ = 12;

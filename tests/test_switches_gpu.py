@@ -19,6 +19,7 @@ SWITCHES = [
     # decomposed solve mixed marching passes with pair passes: the SF_ERR_HALO_EXCEEDED of gpurun_out/ish.log); the
     # slabs keep their four ghost planes, so every pass is a pair launch of boundary depth four
     {"SF_ISHELL": "0"}, {"SF_ISHELL": "0", "SF_GHOST": "3"}, {"SF_ISHELL": "0", "SF_TRAP": "3"},
+    {"SF_ISHELL": "2"},             # as the default, but every solve's last pass writes its i-shell (round 2's rule)
     {"SF_NT": "1"}, {"SF_NT": "0"},  # non-temporal stores everywhere / nowhere (default: beyond the Infinity Cache)
     {"SF_ADVECT_ROW": "0"}, {"SF_ADVECT_ROW": "2"}, {"SF_ADVECT_ROW": "3"},  # advect: one form for every call
     {"SF_OVL": "0"}, {"SF_OVL": "2"},
