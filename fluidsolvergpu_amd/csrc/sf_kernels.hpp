@@ -1712,6 +1712,7 @@ struct AdvectArgs {
     const T* w;
     T dt0;
     int* flag;  // set to 1 if a back-trace left the planes this slab stores
+    int skip_ishell;  // leave the i = 0 / N+1 shell cells of the result unwritten (nobody reads them: Solver::vel_step_body)
 };
 
 template <class T, int NF>
@@ -1788,7 +1789,7 @@ __global__ void __launch_bounds__(256) advect_kernel(Geom g, AdvectArgs<T, NF> A
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
         store_cells<T, W>(A.d[f], q - i0, i0, out[f], nv);
-        emit_shells<T, W>(A.d[f], g, A.b[f], i0, j, kl, out[f], nv);
+        emit_shells<T, W>(A.d[f], g, A.b[f], i0, j, kl, out[f], nv, A.skip_ishell == 0);
     }
 }
 
@@ -1886,7 +1887,7 @@ __global__ void __launch_bounds__(256) advect_row_kernel(Geom g, AdvectArgs<T, N
                  s1 * (t0 * (r0 * c1[f][0] + r1 * c1[f][1]) + t1 * (r0 * c1[f][2] + r1 * c1[f][3]));
         if (ok) {
             A.d[f][q] = out[0];
-            emit_shells<T, 1>(A.d[f], g, A.b[f], i, j, kl, out, 1);
+            emit_shells<T, 1>(A.d[f], g, A.b[f], i, j, kl, out, 1, A.skip_ishell == 0);
         }
     }
     if (bad) atomicOr(A.flag, 1);
@@ -1908,6 +1909,7 @@ struct ProjectArgs {
     // when the solve that produced the field left its i-shell unwritten (Solver::vel_step_body: those 2 N^2 x planes
     // isolated four-byte writes per field are partial writes to HBM and cost a 512^3 last pass 18 %).
     int mirror_u, mirror_p;
+    int skip_div_ishell;  // div's i-shell is never read by the solve; written only where the slot is compared afterwards
 };
 
 template <class T>
@@ -1933,7 +1935,7 @@ __global__ void __launch_bounds__(256) project_div_kernel(Geom g, ProjectArgs<T>
         out[e] = A.c_div * (((right - left) + (vp[e] - vm[e])) + (wp[e] - wm[e]));
     }
     store_cells<T, W>(A.div, q - i0, i0, out, nv);
-    emit_shells<T, W>(A.div, g, 0, i0, j, kl, out, nv);
+    emit_shells<T, W>(A.div, g, 0, i0, j, kl, out, nv, A.skip_div_ishell == 0);
 }
 
 // project, second half: u -= c_grad*dp/di etc., set_bnd(1,u), (2,v), (3,w).

@@ -624,8 +624,11 @@ public:
         swap_slots(SF_U0, SF_U);
         swap_slots(SF_V0, SF_V);
         swap_slots(SF_W0, SF_W);
+        // the advected velocity goes straight into the second projection: same argument as for the diffused one
+        dead_ishell_ = dead;
         op_advect<3>(vel, vel0, b123, SF_U0, SF_V0, SF_W0);
-        op_project(SF_U, SF_V, SF_W, SF_U0, SF_V0);
+        dead_ishell_ = false;
+        op_project(SF_U, SF_V, SF_W, SF_U0, SF_V0, dead, false);
     }
 
     // SPEC §3 dens_step.
@@ -1917,6 +1920,7 @@ private:
             A.w = sl.field[w];
             A.dt0 = dt0;
             A.flag = sl.d_flag;
+            A.skip_ishell = dead_ishell_ ? 1 : 0;
             dim3 block;
             unsigned nblocks;
             const sfk::TileMap m = flat_map(ke - kb, block, nblocks);
@@ -1947,6 +1951,8 @@ private:
     void op_project(int u, int v, int w, int p, int div, bool mirror_u = false, bool dead_p = false) {
         mirror_u = mirror_u && ishell_skip_;
         dead_p = dead_p && ishell_skip_ && K_ >= 1;
+        // (a projection whose pressure is dead is the first one of vel_step: its div slot is overwritten as well)
+        const bool dead_div = dead_p;
         const T Nf = (T)N_;
         const T h = T(1) / Nf;
         auto args = [&](Slab& sl) {
@@ -1960,6 +1966,7 @@ private:
             A.c_grad = T(0.5) * Nf;
             A.mirror_u = mirror_u ? 1 : 0;
             A.mirror_p = dead_p ? 1 : 0;
+            A.skip_div_ishell = dead_div ? 1 : 0;
             return A;
         };
         // p = 0: when the first two sweeps are fused the kernel treats x as literal zeros and p is never read,

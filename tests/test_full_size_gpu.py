@@ -94,11 +94,12 @@ def test_config3_step_full_size():
         assert_same(got[n], want[n], f"config 3 (512^3 f32 K=40): {n}")
 
 
-def test_config4_lin_solve_eight_slabs_vs_oracle():
-    """configs[3]: the 1024^3 fp32 grid in eight k-slabs (logical slabs on one GPU, ghost planes through RCCL
-    send/recv on a single-rank communicator), lin_solve with K = 20 against the ORACLE (not against the one-slab run):
-    128-plane slabs, four ghost planes, first pass + four plain/last four-sweep passes, trapezoid boundary launches."""
-    N, dtype, K = 1024, np.float32, 20
+@pytest.mark.parametrize("N,dtype,K", [(1024, np.float32, 20), (512, np.float64, 40)], ids=["config4-1024-f32-K20", "config5-512-f64-K40"])
+def test_decomposed_configs_lin_solve_eight_slabs_vs_oracle(N, dtype, K):
+    """configs[3] and configs[4] (8 GPUs) of BASELINE.json: the 1024^3 fp32 / 512^3 fp64 grids in eight k-slabs (logical
+    slabs on one GPU, ghost planes through RCCL send/recv on a single-rank communicator), lin_solve with the config's own
+    K against the ORACLE (not against the one-slab run): 128- / 64-plane slabs, four ghost planes, first pass + plain /
+    last four-sweep passes, trapezoid boundary launches."""
     x, x0 = roofline_inputs(N, dtype)
     a, c = 0.3, 1 + 6 * 0.3
     with make(N, dtype, K=K, **slab_kw("rccl-self", 8)) as fs:
@@ -111,4 +112,4 @@ def test_config4_lin_solve_eight_slabs_vs_oracle():
         check_transport(fs, "rccl-self", 8)
         got = fs.download("dens")
     O.lin_solve(0, x, x0, dtype(a), dtype(c), K)
-    assert_same(got, x, "1024^3 lin_solve K=20, 8 slabs (rccl-self) vs oracle")
+    assert_same(got, x, f"{N}^3 lin_solve K={K}, 8 slabs (rccl-self) vs oracle")
