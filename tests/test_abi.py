@@ -79,3 +79,22 @@ def test_driver_rejects_rank_override_without_loopback():
     exe = os.path.join(ROOT, "fluidsolvergpu_amd", "sf_driver")
     out = subprocess.run([exe, "--rank", "1", "--world", "2", "--every", "0"], capture_output=True, text=True, timeout=60)
     assert out.returncode == 2 and "--loopback" in out.stderr
+
+
+def test_switch_table_matches_the_library_and_the_switch_tests():
+    """INTEGRATION.md §5 documents exactly the SF_* switches libsfgpu.so reads (at most twenty), and each of them is
+    exercised by a GPU test (tests/test_switches_gpu.py, or the test the table / that file names)."""
+    src = ""
+    for f in ("sf_solver.hpp", "sf_base.hpp", "sf_api.hip", "sf_kernels.hpp"):
+        src += open(os.path.join(ROOT, "fluidsolvergpu_amd", "csrc", f)).read()
+    read = set(re.findall(r'env_int\("(SF_[A-Z0-9_]+)"', src)) | set(re.findall(r'getenv\("(SF_[A-Z0-9_]+)"\)', src))
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    table = doc[doc.index("## 5. Environment switches"):]
+    documented = set(re.findall(r"^\| `(SF_[A-Z0-9_]+)` \|", table, flags=re.M))
+    assert read == documented, (sorted(read - documented), sorted(documented - read))
+    assert len(documented) <= 20
+    tests = ""
+    for f in ("test_switches_gpu.py", "test_parity_gpu.py", "test_schedule_check.py", "conftest.py"):
+        tests += open(os.path.join(ROOT, "tests", f)).read()
+    missing = [s for s in documented if s not in tests]
+    assert not missing, missing
