@@ -895,6 +895,12 @@ __global__ void __launch_bounds__(256, SF_J2_WAVES) jacobi2_kernel(Geom g, Jacob
 // register state per lane of the 16-byte vectors used elsewhere, which is what lets two waves share a SIMD.
 // A buffer offset that is out of range of every plane resource under either reading of the range check (with or without
 // the instruction's scalar offset, at most a plane, added in): dropped stores, loads that return 0.
+// Diagnostic builds of tools/sk_probe.hip only (the library is built without it): -DSF_SK_DIAG=1 drops the stores of
+// the marching loop, 3 replaces its loads by register copies, 4 does both — what does a march step cost with no memory
+// operation in it? (profiles/r03_marching_kernel_experiments.md §6: 88 % of the full step.) Results are garbage.
+#ifndef SF_SK_DIAG
+#define SF_SK_DIAG 0
+#endif
 constexpr unsigned SK_OOB = 0x80000000u;
 // Rows of padding the host allocates before / after every field for the marching kernel: the rows of a workgroup's tile
 // are addressed as (row 0 of the lane) + r rows, not clamped into the plane, so the first j-block reaches S-1 rows
@@ -1168,7 +1174,11 @@ __device__ __forceinline__ void jsk_step(const Geom& g, SkShared<T, WL, S, TJ, N
         constexpr int slot = XSH ? 2 : ((PH + 2) & 3);
         if constexpr (FIRST != 3) {
 #pragma unroll
+#if SF_SK_DIAG == 3 || SF_SK_DIAG == 4
+            for (int r = 0; r < TJ; ++r) { xr[slot][r] = xr[0][r]; asm volatile("" : "+v"(xr[slot][r])); }
+#else
             for (int r = 0; r < TJ; ++r) xr[slot][r] = buf_load<T, WL>(rd, rv(r), rs_(r));
+#endif
         }
         if constexpr ((FIRST == 1 || FIRST == 2) && ROWEND) {
 #pragma unroll
@@ -1192,7 +1202,11 @@ __device__ __forceinline__ void jsk_step(const Geom& g, SkShared<T, WL, S, TJ, N
 #pragma unroll
                 for (int r = 0; r < TJ; ++r) sr[l][r] = sr[l - 1][r];
 #pragma unroll
+#if SF_SK_DIAG == 3 || SF_SK_DIAG == 4
+            for (int r = 0; r < TJ; ++r) { sr[0][r] = sr[4][r]; asm volatile("" : "+v"(sr[0][r])); }
+#else
             for (int r = 0; r < TJ; ++r) sr[0][r] = buf_load<T, WL>(rs, rv(r), rs_(r));
+#endif
         } else {
 #pragma unroll
             for (int r = 0; r < TJ; ++r) sr[(PH + 1) & 3][r] = buf_load<T, WL>(rs, rv(r), rs_(r));
@@ -1247,8 +1261,6 @@ __device__ __forceinline__ void jsk_step(const Geom& g, SkShared<T, WL, S, TJ, N
         // source level l-1 on planes kk-l (km), kk-l+1 (centre), kk-l+2 (kp); this level's plane is kk-l+1
         const int pl = kk - l + 1;
         const int kg = g.kg0 + pl;
-        // k walls are handled in every instantiation: wave-uniform tests, true in at most S-1 steps per chunk end
-        const bool klo = l >= 2 && g.wall_lo && kg == 1, khi = l >= 2 && g.wall_hi && kg == N;
         T* __restrict__ po = pout;  // plane kk-S+1: only used by level S
         const __amdgpu_buffer_rsrc_t rc = prs(po);
         if constexpr (S == 4) {
@@ -1267,6 +1279,7 @@ __device__ __forceinline__ void jsk_step(const Geom& g, SkShared<T, WL, S, TJ, N
                 }
             }
         }
+        VW olast[TJ];  // level S: the rows as stored
 #pragma unroll
         for (int r = 0; r < TJ; ++r) {
             VW cc, km, kp, jm, jp;
@@ -1327,13 +1340,11 @@ __device__ __forceinline__ void jsk_step(const Geom& g, SkShared<T, WL, S, TJ, N
                     if (at_jlo(r)) jm = sy * cc;
                     if (at_jhi(r)) jp = sy * cc;
                 }
-                if (klo) km = sz * cc;
-                if (khi) kp = sz * cc;
             }
             const VW s = (S == 4) ? sr[l < 5 ? l : 0][r] : sr[(PH + 5 - l) & 3][r];
-            VW o;
-#pragma unroll
-            for (int e = 0; e < WL; ++e) o[e] = (s[e] + a * ((lr[e] + (jm[e] + jp[e])) + (km[e] + kp[e]))) * inv;
+            // (whole lane vectors: the two cells of a lane pair up in the packed instructions — left to itself the SLP
+            // vectoriser pairs cells of different rows and pays for it in register moves)
+            const VW o = (s + a * ((lr + (jm + jp)) + (km + kp))) * inv;
             if (l < S) {
                 yr[l - 1 < S - 1 ? l - 1 : 0][YSH ? 0 : ((PH + 5 - l) & 3) % (S == 4 ? 3 : 4)][r] = o;
             } else {
@@ -1357,28 +1368,14 @@ __device__ __forceinline__ void jsk_step(const Geom& g, SkShared<T, WL, S, TJ, N
                     const unsigned offsh = (SHELL && offv != OOB && first_vec) ? offv - (unsigned)sizeof(T)
                                            : ((SHELL && offv != OOB && last_vec) ? offv + WL * (unsigned)sizeof(T) : OOB);
                     const T osh = first_vec ? o[0] : o[WL - 1];
+#if SF_SK_DIAG == 1 || SF_SK_DIAG == 4
+                    asm volatile("" ::"v"(o));
+#else
                     buf_store<T, WL, NT>(rc, offv, o, so);
+#endif
                     if constexpr (SHELL) buf_store1<T>(rc, offsh, sx * osh, so);
-                    // first / last plane of a wall slab (wave-uniform, one step per chunk end): the k face of this row
-                    // and, with the i-shell, its two i-k edge cells — the expressions of emit_shells
+                    olast[r] = o;  // (the k faces of a first / last plane are stored after the rows, below)
                     const bool kslo = g.wall_lo && kg == 1, kshi = g.wall_hi && kg == N;
-                    if (kslo | kshi) {
-                        const T half = T(0.5);
-                        VW t;
-#pragma unroll
-                        for (int e = 0; e < WL; ++e) t[e] = sz * o[e];
-                        const T esh = half * (sz * osh + sx * osh);  // the i-k edge cell of that row end
-                        if (kslo) {
-                            const __amdgpu_buffer_rsrc_t rk = prs(po - g.plane);
-                            buf_store<T, WL, false>(rk, offv, t, so);
-                            if constexpr (SHELL) buf_store1<T>(rk, offsh, esh, so);
-                        }
-                        if (kshi) {
-                            const __amdgpu_buffer_rsrc_t rk = prs(po + g.plane);
-                            buf_store<T, WL, false>(rk, offv, t, so);
-                            if constexpr (SHELL) buf_store1<T>(rk, offsh, esh, so);
-                        }
-                    }
                     if constexpr (WALLS) {
                         // a row next to a j wall (per lane; no lane in most waves and steps, so the branch is skipped):
                         // the j face cell of every interior cell of the row, the i-j edge cells at a row end, and on a
@@ -1411,6 +1408,52 @@ __device__ __forceinline__ void jsk_step(const Geom& g, SkShared<T, WL, S, TJ, N
                                 }
                             }
                         }
+                    }
+                }
+            }
+        }
+        if (l < S) {
+            // set_bnd of this level on the k walls, where the next level reads it: the plane below the first one is
+            // sz x (first plane), the plane above the last one sz x (last plane). Wave-uniform and true in one step per
+            // level and chunk end, so it is a branch around register moves (no memory operation inside), taken by
+            // everybody or nobody: the rows themselves carry no k-wall selects.
+            constexpr int NS = S == 4 ? 3 : 4;
+            const int s_new = YSH ? 0 : (((PH + 5 - l) & 3) % NS), s_old = YSH ? 1 : (((PH + 4 - l) & 3) % NS);
+            const bool fix_lo = g.wall_lo && kg == 1, fix_hi = g.wall_hi && kg == N + 1;
+            if (fix_lo | fix_hi) {
+                asm volatile("; k-wall planes of level %0" ::"n"(l));  // (keeps the branch a branch: no if-conversion into selects)
+                const int q = l - 1 < S - 1 ? l - 1 : 0;
+#pragma unroll
+                for (int r = 0; r < TJ; ++r) {
+                    if (fix_lo) yr[q][s_old][r] = sz * yr[q][s_new][r];
+                    if (fix_hi) yr[q][s_new][r] = sz * yr[q][s_old][r];
+                }
+            }
+        } else {
+            // first / last plane of a wall slab (wave-uniform, one step per chunk end): the k face of every row and,
+            // with the i-shell, its two i-k edge cells — the expressions of emit_shells
+            const bool kslo = g.wall_lo && kg == 1, kshi = g.wall_hi && kg == N;
+            if (kslo | kshi) {
+                constexpr bool SHELL = ISH && ROWEND;
+                const __amdgpu_buffer_rsrc_t rlo = prs(po - g.plane), rhi = prs(po + g.plane);
+#pragma unroll
+                for (int r = 0; r < TJ; ++r) {
+                    const unsigned offv = st_off(r), so = rs_(r);
+                    const unsigned offsh = (SHELL && offv != SK_OOB && first_vec) ? offv - (unsigned)sizeof(T)
+                                           : ((SHELL && offv != SK_OOB && last_vec) ? offv + WL * (unsigned)sizeof(T) : SK_OOB);
+                    const T half = T(0.5);
+                    const T osh = first_vec ? olast[r][0] : olast[r][WL - 1];
+                    const T esh = half * (sz * osh + sx * osh);  // the i-k edge cell of that row end
+                    VW t;
+#pragma unroll
+                    for (int e = 0; e < WL; ++e) t[e] = sz * olast[r][e];
+                    if (kslo) {
+                        buf_store<T, WL, false>(rlo, offv, t, so);
+                        if constexpr (SHELL) buf_store1<T>(rlo, offsh, esh, so);
+                    }
+                    if (kshi) {
+                        buf_store<T, WL, false>(rhi, offv, t, so);
+                        if constexpr (SHELL) buf_store1<T>(rhi, offsh, esh, so);
                     }
                 }
             }
@@ -1598,12 +1641,9 @@ __device__ __forceinline__ void jsk_march(const Geom& g, SkShared<T, WL, S, TJ, 
 #endif
 }
 
-#ifndef SF_SK_WAVES
-#define SF_SK_WAVES 2
-#endif
 
 template <class T, int NF, int WL, bool NT, int S, int TJ, int NW, bool ISH, int FIRST = 0>
-__global__ void __launch_bounds__(64 * NW, SF_SK_WAVES) jacobi_sk_kernel(Geom g, JacobiArgs<T, NF> A, int kb, int ke,
+__global__ void __launch_bounds__(64 * NW, (NW + 3) / 4) jacobi_sk_kernel(Geom g, JacobiArgs<T, NF> A, int kb, int ke,
                                                                          SkMap m) {
     // Every sweep level loses one CELL of validity per side in i, so after S levels ceil(S / WL) lanes per side hold
     // at least one invalid cell and only feed the shuffles

@@ -1481,6 +1481,14 @@ private:
         }
         return nchunk;
     }
+#ifndef SF_SK4_TJ
+#define SF_SK4_TJ 2
+#define SF_SK4_NW 16
+#endif
+#ifndef SF_SK4F_TJ
+#define SF_SK4F_TJ SF_SK4_TJ
+#define SF_SK4F_NW SF_SK4_NW
+#endif
     template <bool NT, int S, int TJ, int NW, int FIRST = 0>
     void launch_sk_cfg(Slab& sl, const sfk::JacobiArgs<T, 1>& A, int kb, int ke, bool last) {
         constexpr int WL = W / 2;  // 8 bytes per lane
@@ -1524,7 +1532,7 @@ private:
                         (nt_mode_ == 2 && (size_t)field_elems_ * sizeof(T) * 3 * NF > ((size_t)384 << 20));
         // rows per wave: four; five in fp64 for the zero-iterate pass (no x ring to fill — the passes that read the
         // caller's i-shell hold a ring of shell cells on top and spill at five)
-        constexpr int TJ0 = 4, TJ3 = sizeof(T) == 4 ? 4 : 5;
+        constexpr int TJ0 = SF_SK4F_TJ, NWF = SF_SK4F_NW, TJ3 = SF_SK4_TJ, NW4 = SF_SK4_NW;
         for (int f = 0; f < NF; ++f) {
             sfk::JacobiArgs<T, 1> B;
             B.x[0] = A.x[f];
@@ -1536,14 +1544,14 @@ private:
             B.inv = A.inv;
             B.dt = A.dt;
             if (mode == 1) {
-                if (nt) launch_sk_cfg<true, 4, TJ0, 8, 1>(sl, B, kb, ke, false);
-                else launch_sk_cfg<false, 4, TJ0, 8, 1>(sl, B, kb, ke, false);
+                if (nt) launch_sk_cfg<true, 4, TJ0, NWF, 1>(sl, B, kb, ke, false);
+                else launch_sk_cfg<false, 4, TJ0, NWF, 1>(sl, B, kb, ke, false);
             } else if (mode == 2) {
-                if (nt) launch_sk_cfg<true, 4, TJ0, 8, 2>(sl, B, kb, ke, false);
-                else launch_sk_cfg<false, 4, TJ0, 8, 2>(sl, B, kb, ke, false);
+                if (nt) launch_sk_cfg<true, 4, TJ0, NWF, 2>(sl, B, kb, ke, false);
+                else launch_sk_cfg<false, 4, TJ0, NWF, 2>(sl, B, kb, ke, false);
             } else {
-                if (nt) launch_sk_cfg<true, 4, TJ3, 8, 3>(sl, B, kb, ke, false);
-                else launch_sk_cfg<false, 4, TJ3, 8, 3>(sl, B, kb, ke, false);
+                if (nt) launch_sk_cfg<true, 4, TJ3, NW4, 3>(sl, B, kb, ke, false);
+                else launch_sk_cfg<false, 4, TJ3, NW4, 3>(sl, B, kb, ke, false);
             }
         }
     }
@@ -1575,11 +1583,11 @@ private:
             // a spill of nine registers in the wall workgroups alone doubled the launch at 256^3, where every
             // workgroup runs at once and the slowest one is the launch). Tile shapes 4 x 4, 6 x 4 and 4 x 8 (rows x
             // waves) were measured within +-5 % at 512^3 and 10-25 % behind at 256^3 in round 2 and removed.
-            constexpr int TJ0 = S == 4 ? (sizeof(T) == 4 ? 4 : 5) : 6;
+            constexpr int TJ0 = S == 4 ? SF_SK4_TJ : 6, NW0 = S == 4 ? SF_SK4_NW : 8;
             if (nt)
-                launch_sk_cfg<true, S, TJ0, 8>(sl, B, kb, ke, last);
+                launch_sk_cfg<true, S, TJ0, NW0>(sl, B, kb, ke, last);
             else
-                launch_sk_cfg<false, S, TJ0, 8>(sl, B, kb, ke, last);
+                launch_sk_cfg<false, S, TJ0, NW0>(sl, B, kb, ke, last);
         }
     }
 

@@ -6,6 +6,9 @@
 // mean cycles per step and wave spent in: issuing the requests | level 1 (first use of the planes requested one step
 // ago) | levels 2..4 + stores | publishing the edge rows | the barrier.
 // Build: hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -std=c++17 -DSF_SK_STAMP tools/sk_probe.hip -o tools/sk_probe
+// Options: -DPROBE_TJ=<rows per wave> -DPROBE_NW=<waves per workgroup> (default: the library's 2 x 16; 4 x 8 is the
+// round-2 tile); -DSF_SK_DIAG=1|3|4 drops the stores / the loads / both of the marching loop (garbage results: timing
+// only); without -DSF_SK_STAMP the launch times carry no stamp overhead (~10 %).
 #include "../fluidsolvergpu_amd/csrc/sf_kernels.hpp"
 
 #include <algorithm>
@@ -14,6 +17,12 @@
 #include <cstring>
 #include <vector>
 
+#ifndef PROBE_TJ
+#define PROBE_TJ 2
+#endif
+#ifndef PROBE_NW
+#define PROBE_NW 16
+#endif
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
 static int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
@@ -21,7 +30,7 @@ static int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 template <bool NT>
 void run(int N, const char* what, int gx, int gy, int gz_override) {
     typedef float T;
-    constexpr int WL = 2, S = 4, TJ = 4, NW = 8, W = 4;
+    constexpr int WL = 2, S = 4, TJ = PROBE_TJ, NW = PROBE_NW, W = 4;
     constexpr int V = NW * TJ - 2 * S, P = 64 - 2 * ((S + WL - 1) / WL);
     sfk::Geom g{};
     g.N = N; g.nzl = N; g.G = 1; g.np = N + 2; g.kg0 = 0; g.lead = 32;
