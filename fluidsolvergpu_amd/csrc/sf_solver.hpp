@@ -1481,14 +1481,16 @@ private:
         }
         return nchunk;
     }
-#ifndef SF_SK4_TJ
-#define SF_SK4_TJ 2
-#define SF_SK4_NW 16
-#endif
-#ifndef SF_SK4F_TJ
-#define SF_SK4F_TJ SF_SK4_TJ
-#define SF_SK4F_NW SF_SK4_NW
-#endif
+    // Tile of the four-sweep launches (rows per wave x waves stacked in j; the lane vector is 8 bytes in both types).
+    // fp32: 2 x 16 — four waves per SIMD at <= 128 registers: a march step is bound by each wave's serial instruction
+    // stream (tools/sk_probe.hip -DSF_SK_DIAG=4: 88 % of its time with every load and store removed), so 16 thin waves
+    // beat 8 waves of four rows (256^3: 62 -> 59 us per pass, 512^3: 441 -> 392, same 32-row tile and bytes).
+    // fp64: 5 x 8 — half the cells per lane, twice the bytes per cell: there the 40-row tile (32 rows stored instead
+    // of 24 of 32) is worth more than the waves (512^3 K = 40 step: 50.5 against 56.4 ms).
+    // First passes over caller data (FIRST = 1, 2) hold a ring of shell cells and the right-hand side on top and
+    // spill at 128 registers: 4 x 8 in both types.
+    static constexpr int SK4_TJ = sizeof(T) == 4 ? 2 : 5, SK4_NW = sizeof(T) == 4 ? 16 : 8;
+    static constexpr int SK4F_TJ = 4, SK4F_NW = 8;
     template <bool NT, int S, int TJ, int NW, int FIRST = 0>
     void launch_sk_cfg(Slab& sl, const sfk::JacobiArgs<T, 1>& A, int kb, int ke, bool last) {
         constexpr int WL = W / 2;  // 8 bytes per lane
@@ -1530,9 +1532,8 @@ private:
     void launch_sk_first(Slab& sl, const sfk::JacobiArgs<T, NF>& A, int kb, int ke, int mode) {
         const bool nt = nt_mode_ == 1 ||
                         (nt_mode_ == 2 && (size_t)field_elems_ * sizeof(T) * 3 * NF > ((size_t)384 << 20));
-        // rows per wave: four; five in fp64 for the zero-iterate pass (no x ring to fill — the passes that read the
-        // caller's i-shell hold a ring of shell cells on top and spill at five)
-        constexpr int TJ0 = SF_SK4F_TJ, NWF = SF_SK4F_NW, TJ3 = SF_SK4_TJ, NW4 = SF_SK4_NW;
+        // (tiles: SK4F_* for the passes that read the caller's i-shell, SK4_* for the zero-iterate pass, see above)
+        constexpr int TJ0 = SK4F_TJ, NWF = SK4F_NW, TJ3 = SK4_TJ, NW4 = SK4_NW;
         for (int f = 0; f < NF; ++f) {
             sfk::JacobiArgs<T, 1> B;
             B.x[0] = A.x[f];
@@ -1577,13 +1578,10 @@ private:
             B.b[0] = A.b[f];
             B.a = A.a;
             B.inv = A.inv;
-            // Tile: eight waves stacked in j; rows per wave: six at S <= 3, four in fp32 / five in fp64 at S = 4.
-            // Four levels hold 17 planes of rows per lane (x 3, x0 5, three intermediate levels x 3). Five rows per
-            // wave fit 256 registers only just in fp32 and buy nothing (446 vs 431 us at 512^3, 67.9 vs 66.1 at 256^3;
-            // a spill of nine registers in the wall workgroups alone doubled the launch at 256^3, where every
-            // workgroup runs at once and the slowest one is the launch). Tile shapes 4 x 4, 6 x 4 and 4 x 8 (rows x
-            // waves) were measured within +-5 % at 512^3 and 10-25 % behind at 256^3 in round 2 and removed.
-            constexpr int TJ0 = S == 4 ? SF_SK4_TJ : 6, NW0 = S == 4 ? SF_SK4_NW : 8;
+            // Tile: SK4_* at S = 4 (above); six rows x eight waves at S <= 3. Four levels hold 17 planes of rows per
+            // lane (x 3, x0 5, three intermediate levels x 3). (A spill in the wall workgroups alone doubles a launch
+            // at 256^3, where every workgroup runs at once and the slowest one is the launch.)
+            constexpr int TJ0 = S == 4 ? SK4_TJ : 6, NW0 = S == 4 ? SK4_NW : 8;
             if (nt)
                 launch_sk_cfg<true, S, TJ0, NW0>(sl, B, kb, ke, last);
             else

@@ -37,7 +37,7 @@ void run(int N, const char* what, int gx, int gy, int gz_override) {
     g.px = ceil_div(g.lead + N + 1 + W, 32) * 32;
     g.plane = (long)g.px * (N + 2);
     g.wall_lo = g.wall_hi = 1;
-    const long elems = g.plane * g.np + 256, front = (4L * g.px + 63) / 64 * 64, back = 64L * g.px;
+    const long elems = g.plane * g.np + 256, front = (4L * g.plane + 4L * g.px + 63) / 64 * 64, back = 4L * g.plane + 64L * g.px;
     T *x, *x0, *xn;
     const size_t bytes = (size_t)(front + elems + back) * sizeof(T);
     CK(hipMalloc(&x, bytes)); CK(hipMalloc(&x0, bytes)); CK(hipMalloc(&xn, bytes));
@@ -52,7 +52,6 @@ void run(int N, const char* what, int gx, int gy, int gz_override) {
     const int nvec = N / WL;
     m.njb = ceil_div(N, V);
     m.ncb = ceil_div((long)m.njb * nvec, P);
-    m.band = ceil_div(m.ncb, 8);
     m.nvec_magic = 0xFFFFFFFFu / (unsigned)nvec + 1u;
     const int kb = 1, ke = 1 + N, np = N;
     int nchunk = 1;
@@ -67,6 +66,7 @@ void run(int N, const char* what, int gx, int gy, int gz_override) {
     }
     m.kc = ceil_div(np, nchunk);
     nchunk = ceil_div(np, m.kc);
+    m.band = ceil_div(m.ncb, 8);
     dim3 grid(gx > 0 ? gx : 8, gy > 0 ? gy : m.band, gz_override > 0 ? gz_override : nchunk);
     const long nwg = (long)grid.x * grid.y * grid.z;
     unsigned long long* d_st;
@@ -94,7 +94,7 @@ void run(int N, const char* what, int gx, int gy, int gz_override) {
     if (gz_override == 0 && gx == 0) {  // whole grid: checksum of the output (variants must agree bit for bit)
         std::vector<T> h((size_t)(front + elems + back));
         CK(hipMemcpy(h.data(), xn, bytes, hipMemcpyDeviceToHost));
-        for (size_t q = 0; q < h.size(); ++q) {
+        for (size_t q = (size_t)front; q < (size_t)(front + elems); ++q) {  // (the field itself, not its padding)
             unsigned u;
             memcpy(&u, &h[q], 4);
             sum_bits = (sum_bits ^ u) * 1099511628211ull;
