@@ -892,7 +892,8 @@ __global__ void __launch_bounds__(256, SF_J2_WAVES) jacobi2_kernel(Geom g, Jacob
 }
 
 // Lane vector of the marching kernel (jacobi_sk_kernel below): WL cells = 8 bytes (two floats / one double) — half the
-// register state per lane of the 16-byte vectors used elsewhere, which is what lets two waves share a SIMD.
+// register state per lane of the 16-byte vectors used elsewhere, which is what lets two waves share a SIMD — four with
+// two rows per wave (fp32 four-sweep launches: 16 waves per workgroup, Solver::SK4_TJ / SK4_NW).
 // A buffer offset that is out of range of every plane resource under either reading of the range check (with or without
 // the instruction's scalar offset, at most a plane, added in): dropped stores, loads that return 0.
 // Diagnostic builds of tools/sk_probe.hip only (the library is built without it): -DSF_SK_DIAG=1 drops the stores of

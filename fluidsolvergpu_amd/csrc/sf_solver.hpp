@@ -1452,7 +1452,7 @@ private:
     // k-marching S-sweep kernel (sfk::jacobi_sk_kernel): the plain passes of a solve (iterate already swept once, so its
     // i-shell is recomputed in registers) on plane ranges long enough to march. SF_MARCH=0 switches it off.
     bool can_march_k(int nplanes, bool first) const {
-        // small grids do not fill the chip with 512-thread workgroups of 48 rows (128^3: 9.0 vs 4.3 us/sweep)
+        // small grids do not fill the chip with workgroups of 32-48 rows (128^3: 9.0 vs 4.3 us/sweep)
         return march_k_ != 0 && !first && ishell_skip_ && split_ == INT_MAX && nplanes >= march_min_planes_ &&
                !x_is_zero_ && (long)N_ * N_ * nplanes >= march_min_cells_;
     }
