@@ -185,7 +185,11 @@ public:
         graphs_ = env_int("SF_GRAPH", 0) != 0 && P_ == 1;
         march_k_ = env_int("SF_MARCH", 1);  // 0: the register-blocked pair kernel everywhere
         march_min_planes_ = env_int("SF_MARCH_MINP", 12);
-        march_min_cells_ = (long)env_int("SF_MARCH_MINCELLS_K", 6000) * 1000L;  // ~182^3
+        // Smallest launch the marching kernel takes. Slab interiors: 6 M cells (~182^3 worth; thin slabs pay chunk ends).
+        // Undecomposed grids: 2.5 M (~136^3) — with 16 thin waves per workgroup it overtakes the pair kernel there
+        // (us per sweep of a 20-sweep solve, pair / marching: 128^3 4.4 / 5.8, 144^3 9.0 / 6.0, 160^3 10.6 / 6.3,
+        // 176^3 13.4 / 7.1). SF_MARCH_MINCELLS_K sets both.
+        march_min_cells_ = (long)env_int("SF_MARCH_MINCELLS_K", P_ == 1 ? 2500 : 6000) * 1000L;
         sk2_min_cells_ = std::max(march_min_cells_ == 0 ? 0L : 60000000L, march_min_cells_);  // ~390^3
         sk_s_ = env_int("SF_SK_S", 4);
         sk_first_ = env_int("SF_SK_FIRST", 1) != 0;  // first pass of a solve through the marching kernel

@@ -27,11 +27,13 @@ class Schedule:
     sk_first_ok; can_fuse2). Defaults = the library's defaults; keyword arguments = its SF_* switches."""
 
     def __init__(self, N, P, wsize=4, march=1, sk_s=4, sk_first=1, ishell=1, ghost=4, split=1, march_minp=12,
-                 march_mincells_k=6000, fuse2=1, fuse_src=1, zero_skip=1, split_fields=1):
+                 march_mincells_k=None, fuse2=1, fuse_src=1, zero_skip=1, split_fields=1):
         self.N, self.P, self.W = N, P, 16 // wsize
         self.wsize = wsize
         self.nzl = N // P
         self.march, self.sk_s, self.sk_first, self.ishell = march, sk_s, sk_first, ishell
+        if march_mincells_k is None:  # the library's default: 2.5 M cells on one slab, 6 M on a decomposed grid
+            march_mincells_k = 2500 if P == 1 else 6000
         self.split, self.minp, self.mincells = split, march_minp, march_mincells_k * 1000
         self.sk2_mincells = max(60000000 if self.mincells else 0, self.mincells)
         self.fuse2, self.fuse_src, self.zero_skip, self.split_fields = fuse2, fuse_src, zero_skip, split_fields

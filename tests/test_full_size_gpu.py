@@ -59,6 +59,17 @@ def test_config2_full_size():
     assert np.isfinite(got["dens"]).all() and got["dens"].max() > 1.0
 
 
+def test_mid_size_default_thresholds():
+    """144^3 fp32, K = 20, default switches: since round 3 an undecomposed grid of >= 2.5 M cells (here 3.0 M) runs every
+    pass of its solves on the four-sweep marching kernel (SF_MARCH_MINCELLS_K default 2500; 6 M before) — the smallest
+    size class that does, with the most chunk ends per plane. One step of the benchmark inputs against the oracle."""
+    got, want = run_bench_steps(144, np.float32, 20, 1)
+    for n in got:
+        assert_same(got[n], want[n], f"144^3 f32 K=20, default thresholds: {n}")
+    with make(144, np.float32, K=20) as fs:
+        assert fs.lin_solve_launches(20) == 5  # five four-sweep marching launches, no pair launch
+
+
 def roofline_inputs(N, dtype):
     """The inputs of bench.py's roofline leg (time_lin_solve): one random plane scaled per k."""
     rng = np.random.RandomState(1)
