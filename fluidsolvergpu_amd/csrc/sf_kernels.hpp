@@ -1706,6 +1706,7 @@ __global__ void __launch_bounds__(64 * NW, (NW + 3) / 4) jacobi_sk_kernel(Geom g
             x = A.x[ff];
             x0 = A.x0[ff];
             xn = A.xn[ff];
+            x0out = FIRST == 2 ? A.x0out[ff] : A.xn[ff];
             b = A.b[ff];
         }
     const T sx = (b == 1) ? T(-1) : T(1);

@@ -1495,8 +1495,8 @@ private:
     // spill at 128 registers: 4 x 8 in both types.
     static constexpr int SK4_TJ = sizeof(T) == 4 ? 2 : 5, SK4_NW = sizeof(T) == 4 ? 16 : 8;
     static constexpr int SK4F_TJ = 4, SK4F_NW = 8;
-    template <bool NT, int S, int TJ, int NW, int FIRST = 0>
-    void launch_sk_cfg(Slab& sl, const sfk::JacobiArgs<T, 1>& A, int kb, int ke, bool last) {
+    template <bool NT, int S, int TJ, int NW, int FIRST = 0, int NF = 1>
+    void launch_sk_cfg(Slab& sl, const sfk::JacobiArgs<T, NF>& A, int kb, int ke, bool last) {
         constexpr int WL = W / 2;  // 8 bytes per lane
         constexpr int V = NW * TJ - 2 * S, P = 64 - 2 * ((S + WL - 1) / WL);
         const int nvec = N_ / WL;
@@ -1515,13 +1515,15 @@ private:
         } else {
             // The kernel is bound by the bytes a CU can request per unit time, so workgroups that share a CU share its
             // rate: time ~ (workgroups per CU, rounded up) x (steps per chunk: kc + 2S-2, plus start-up).
-            nchunk = sk_chunks(m.ncb, np, S);
+            nchunk = sk_chunks(m.ncb * NF, np, S);  // (NF fields in one grid: NF times the column blocks)
         }
         m.kc = split_ != INT_MAX ? split_ : ceil_div(np, nchunk);
         nchunk = ceil_div(np, m.kc);
-        dim3 nb(8u, (unsigned)m.band, (unsigned)nchunk);
+        dim3 nb(8u, (unsigned)m.band, (unsigned)(nchunk * NF));
         if constexpr (FIRST != 0) {  // a first pass is never the last one (sk_first_ok)
-            launch_k(sl, sfk::jacobi_sk_kernel<T, 1, WL, NT, S, TJ, NW, false, FIRST>, nb, 64u * NW, sl.geom, A, kb, ke, m);
+            launch_k(sl, sfk::jacobi_sk_kernel<T, NF, WL, NT, S, TJ, NW, false, FIRST>, nb, 64u * NW, sl.geom, A, kb, ke, m);
+        } else if constexpr (NF > 1) {  // (fields in one grid: plain passes only, launch_sk)
+            launch_k(sl, sfk::jacobi_sk_kernel<T, NF, WL, NT, S, TJ, NW, false>, nb, 64u * NW, sl.geom, A, kb, ke, m);
         } else {
             if (last)
                 launch_k(sl, sfk::jacobi_sk_kernel<T, 1, WL, NT, S, TJ, NW, true>, nb, 64u * NW, sl.geom, A, kb, ke, m);
@@ -1538,6 +1540,13 @@ private:
                         (nt_mode_ == 2 && (size_t)field_elems_ * sizeof(T) * 3 * NF > ((size_t)384 << 20));
         // (tiles: SK4F_* for the passes that read the caller's i-shell, SK4_* for the zero-iterate pass, see above)
         constexpr int TJ0 = SK4F_TJ, NWF = SK4F_NW, TJ3 = SK4_TJ, NW4 = SK4_NW;
+        if constexpr (NF > 1) {
+            if (mode == 2 && fields_in_one_grid()) {
+                if (nt) launch_sk_cfg<true, 4, TJ0, NWF, 2, NF>(sl, A, kb, ke, false);
+                else launch_sk_cfg<false, 4, TJ0, NWF, 2, NF>(sl, A, kb, ke, false);
+                return;
+            }
+        }
         for (int f = 0; f < NF; ++f) {
             sfk::JacobiArgs<T, 1> B;
             B.x[0] = A.x[f];
@@ -1569,11 +1578,43 @@ private:
         return G_ >= 4 && split_enabled_ && interior >= march_min_planes_ && (long)N_ * N_ * interior >= march_min_cells_;
     }
 
+    // The NF fields of a batched solve (u, v, w of a diffusion) as ONE marching grid on an undecomposed slab: NF times
+    // the column blocks let the launch fill the chip with NF times fewer, longer chunks — a chunk pays 2(S-1) warm-up
+    // planes whatever its length (256^3: 3 chunks of 86 planes instead of 10 of 26 per field: 92 instead of 96 steps per
+    // workgroup; plain pass 51.3 against 53.3 us per field, folded-source first pass 74 against 86).
+    struct BatchScope {  // sets batch_now_ for the launches of one solve
+        bool& flag;
+        bool saved;
+        BatchScope(bool& f, bool v) : flag(f), saved(f) { flag = v; }
+        ~BatchScope() { flag = saved; }
+    };
+    bool fields_in_one_grid() const { return P_ == 1 && split_ == INT_MAX && split_fields_ != 2 && batch_now_; }
+    // ... which the solve only asks for when every pass is a four-sweep marching launch (K a multiple of four on a
+    // grid the kernel takes): a pair-kernel pass over three fields at once would leave the Infinity Cache. And only
+    // where it was measured to pay (same-box A/B of the full step, fields apart / in one grid): 256^3 2.17 / 2.09 ms,
+    // 512^3 K = 40 25.64 / 25.35; not at 160^3 (0.846 / 0.881: one field's three arrays sit in L2 + Infinity Cache
+    // there), not at 1024^3 (121.8 / 123.5) or 512^3 fp64 (49.6 / 49.8), whose chunks are long anyway.
+    bool batch_march(int K, bool continued) const {
+        if (!(P_ == 1 && split_fields_ != 2 && K % 4 == 0 && K >= 4 && sk_first_ && march_k_ != 0 && sk_s_ >= 4 &&
+              can_fuse2() && ishell_skip_ && nzl_ >= march_min_planes_ && (long)N_ * N_ * nzl_ >= march_min_cells_))
+            return false;
+        const double one = 3.0 * (double)(N_ + 2) * (N_ + 2) * nplanes_ * sizeof(T);  // x, x0, x' of one field
+        if (split_fields_ == 1 && (one < 96.0 * 1048576.0 || one > 2048.0 * 1048576.0)) return false;
+        return continued || K >= 8;
+    }
+
     template <int NF, int S>
     void launch_sk(Slab& sl, const sfk::JacobiArgs<T, NF>& A, int kb, int ke, bool last) {
         SF_REQUIRE(ishell_skip_ && march_k_ != 0, "internal: marching launch while SF_ISHELL=0 / SF_MARCH=0");
         const bool nt = nt_mode_ == 1 ||
                         (nt_mode_ == 2 && (size_t)field_elems_ * sizeof(T) * 3 * NF > ((size_t)384 << 20));
+        if constexpr (NF > 1 && S == 4) {
+            if (!last && fields_in_one_grid()) {
+                if (nt) launch_sk_cfg<true, S, SK4_TJ, SK4_NW, 0, NF>(sl, A, kb, ke, false);
+                else launch_sk_cfg<false, S, SK4_TJ, SK4_NW, 0, NF>(sl, A, kb, ke, false);
+                return;
+            }
+        }
         for (int f = 0; f < NF; ++f) {  // one launch per field (fields are independent)
             sfk::JacobiArgs<T, 1> B;
             B.x[0] = A.x[f];
@@ -1665,7 +1706,7 @@ private:
             // 3 x 50.8 us against 175.9 us per pair of three fields). Independent fields: same results.
             const double one = 3.0 * (double)(N_ + 2) * (N_ + 2) * nplanes_ * sizeof(T);
             const bool fits = one <= 0.9 * 256.0 * 1048576.0;
-            if (split_fields_ == 2 || (split_fields_ == 1 && fits)) {
+            if (split_fields_ == 2 || (split_fields_ == 1 && fits && !batch_march(K, continued))) {
                 for (int f = 0; f < NF; ++f) {
                     const int xf[1] = {x[f]}, x0f[1] = {x0[f]}, bf[1] = {b[f]};
                     op_lin_solve<1>(xf, x0f, bf, a, c, K, x_zero, continued);
@@ -1673,6 +1714,7 @@ private:
                 return;
             }
         }
+        BatchScope batch_scope(batch_now_, NF > 1 && batch_march(K, continued));
         const T inv = T(1) / c;
         for (Slab& sl : slabs_)
             for (int f = 0; f < NF; ++f) {
@@ -1816,7 +1858,7 @@ private:
         }
         if constexpr (NF > 1) {
             const double one = 3.0 * (double)(N_ + 2) * (N_ + 2) * nplanes_ * sizeof(T);
-            if (split_fields_ == 2 || (split_fields_ == 1 && one <= 0.9 * 256.0 * 1048576.0)) {
+            if (split_fields_ == 2 || (split_fields_ == 1 && one <= 0.9 * 256.0 * 1048576.0 && !batch_march(K, false))) {
                 for (int f = 0; f < NF; ++f) {
                     const int xf[1] = {x[f]}, x0f[1] = {x0[f]}, bf[1] = {b[f]}, sf[1] = {src[f]};
                     op_diffuse_src<1>(xf, x0f, bf, sf, a, c, K);
@@ -1824,6 +1866,7 @@ private:
                 return;
             }
         }
+        BatchScope batch_scope(batch_now_, NF > 1 && batch_march(K, false));
         const T inv = T(1) / c;
         for (Slab& sl : slabs_)
             for (int f = 0; f < NF; ++f) {
@@ -2061,6 +2104,7 @@ private:
     long march_min_cells_ = 6000000, sk2_min_cells_ = 60000000;
     int sk_s_ = 4;
     bool sk_first_ = true;
+    bool batch_now_ = false;  // the running solve launches its NF fields as one marching grid (batch_march)
     long plane_ = 0, field_elems_ = 0, pad_front_ = 0, pad_back_ = 0;
     std::vector<Slab> slabs_;
     FILE* trace_ = nullptr;  // SF_TRACE_SCHEDULE
