@@ -1335,7 +1335,7 @@ __device__ __forceinline__ void jsk_step(const Geom& g, SkShared<T, WL, S, TJ, N
                     lr[e] = left + right;
                 }
             }
-            if (l >= 2) {  // set_bnd of the source level on the j / k walls
+            if (l >= 2) {  // set_bnd of the source level on the j walls (k walls: after the rows of the producing level)
                 if (WALLS) {
                     // (as selects: a wave-uniform branch per row around them measured 7 % slower at 256^3)
                     if (at_jlo(r)) jm = sy * cc;
@@ -1719,8 +1719,8 @@ __global__ void __launch_bounds__(64 * NW, (NW + 3) / 4) jacobi_sk_kernel(Geom g
     const bool first_vec = (vec == 0), last_vec = (vec == nvec - 1);
     // Does this WORKGROUP touch a j wall? (uniform over the workgroup, from its item range, feeder lanes included —
     // they run on the addresses of their own item, and off the walls rows are addressed without clamping: every wave
-    // takes the same instantiation.) j walls live in the first / last j-block. k walls are cheap wave-uniform tests in
-    // every step.
+    // takes the same instantiation.) j walls live in the first / last j-block. k walls: one wave-uniform test per level
+    // and step, after the rows (jsk_step).
     int flo = cb * P - F, fhi = cb * P + P - 1 + F;
     flo = flo < 0 ? 0 : flo;
     fhi = fhi >= total ? total - 1 : fhi;

@@ -1513,8 +1513,8 @@ private:
             nchunk = 2;
             m.gap = gap_;
         } else {
-            // The kernel is bound by the bytes a CU can request per unit time, so workgroups that share a CU share its
-            // rate: time ~ (workgroups per CU, rounded up) x (steps per chunk: kc + 2S-2, plus start-up).
+            // One workgroup per CU at a time (LDS, registers): time ~ (workgroups per CU, rounded up) x (steps per
+            // chunk: kc + 2S-2, plus start-up).
             nchunk = sk_chunks(m.ncb * NF, np, S);  // (NF fields in one grid: NF times the column blocks)
         }
         m.kc = split_ != INT_MAX ? split_ : ceil_div(np, nchunk);
