@@ -454,6 +454,41 @@ def test_diffuse_fields_together_or_one_by_one(split, monkeypatch):
         assert_same(got[n], f[n], f"split={split}: {n}")
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
+@pytest.mark.parametrize("N,K,bound", [(48, 8, True), (66, 12, True), (48, 8, False), (34, 20, True)])
+def test_diffuse_fields_as_one_marching_grid(N, K, bound, dtype, monkeypatch):
+    """u, v, w of a diffusion as ONE grid of the four-sweep marching kernel (round 3; by default only on undecomposed
+    grids of 200^3..550^3, where tests/test_full_size_gpu.py covers it at 256^3): SF_SPLIT_FIELDS=0 applies the rule at
+    every size. K a multiple of four: folded-source first pass over the three fields (bound sources) or one first pass
+    per field (caller data), then plain passes over the three fields, two steps, against the oracle."""
+    monkeypatch.setenv("SF_SPLIT_FIELDS", "0")
+    monkeypatch.setenv("SF_MARCH_MINCELLS_K", "10")
+    monkeypatch.setenv("SF_MARCH_MINP", "4")
+    f = small_velocity(rand_fields(N, dtype, 17 + N + K), N, dtype)
+    src = {n: f[n].copy() for n in ("u0", "v0", "w0", "dens0")}
+    with make(N, dtype, K=K) as fs:
+        for n in NAMES:
+            fs.upload(n, f[n])
+        if bound:
+            for slot, n in (("user0", "u0"), ("user1", "v0"), ("user2", "w0"), ("user3", "dens0")):
+                fs.upload(slot, src[n])
+            fs.bind_sources("user0", "user1", "user2", "user3")
+        for step in range(2):
+            if not bound and step:
+                for n in src:
+                    fs.upload(n, src[n])
+            fs.vel_step()
+            fs.dens_step()
+        fs.sync()
+        got = {n: fs.download(n) for n in ("u", "v", "w", "dens")}
+    for _ in range(2):
+        for n in src:
+            f[n][...] = src[n]
+        O.step(N, f, dtype(DT), dtype(DIFF), dtype(VISC), K)
+    for n in got:
+        assert_same(got[n], f[n], f"one grid N={N} K={K} bound={bound}: {n}")
+
+
 def test_loopback_rank_share_context():
     """SF_FLAG_LOOPBACK_HALO (measurement aid): rank 1 of 4 without a communicator; the values next to the slab faces are
     meaningless by construction, so this only checks that the context works, stays finite and reports the slab it
