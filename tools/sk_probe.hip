@@ -6,7 +6,7 @@
 // mean cycles per step and wave spent in: issuing the requests | level 1 (first use of the planes requested one step
 // ago) | levels 2..4 + stores | publishing the edge rows | the barrier.
 // Build: hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -std=c++17 -DSF_SK_STAMP tools/sk_probe.hip -o tools/sk_probe
-// Options: -DPROBE_TJ=<rows per wave> -DPROBE_NW=<waves per workgroup> (default: the library's 2 x 16; 4 x 8 is the
+// Options: -DPROBE_F64 (double, one cell per lane); -DPROBE_TJ=<rows per wave> -DPROBE_NW=<waves per workgroup> (default: the library's 2 x 16; 4 x 8 is the
 // round-2 tile); -DSF_SK_DIAG=1|3|4 drops the stores / the loads / both of the marching loop (garbage results: timing
 // only); without -DSF_SK_STAMP the launch times carry no stamp overhead (~10 %).
 #include "../fluidsolvergpu_amd/csrc/sf_kernels.hpp"
@@ -29,12 +29,16 @@ static int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 
 template <bool NT>
 void run(int N, const char* what, int gx, int gy, int gz_override) {
+#ifdef PROBE_F64
+    typedef double T;
+#else
     typedef float T;
-    constexpr int WL = 2, S = 4, TJ = PROBE_TJ, NW = PROBE_NW, W = 4;
+#endif
+    constexpr int WL = 8 / (int)sizeof(T), S = 4, TJ = PROBE_TJ, NW = PROBE_NW, W = 16 / (int)sizeof(T);
     constexpr int V = NW * TJ - 2 * S, P = 64 - 2 * ((S + WL - 1) / WL);
     sfk::Geom g{};
-    g.N = N; g.nzl = N; g.G = 1; g.np = N + 2; g.kg0 = 0; g.lead = 32;
-    g.px = ceil_div(g.lead + N + 1 + W, 32) * 32;
+    g.N = N; g.nzl = N; g.G = 1; g.np = N + 2; g.kg0 = 0; g.lead = 128 / (int)sizeof(T);
+    g.px = ceil_div(g.lead + N + 1 + W, 128 / (int)sizeof(T)) * (128 / (int)sizeof(T));
     g.plane = (long)g.px * (N + 2);
     g.wall_lo = g.wall_hi = 1;
     const long elems = g.plane * g.np + 256, front = (4L * g.plane + 4L * g.px + 63) / 64 * 64, back = 4L * g.plane + 64L * g.px;
@@ -77,7 +81,7 @@ void run(int N, const char* what, int gx, int gy, int gz_override) {
 #endif
     sfk::JacobiArgs<T, 1> A{};
     A.x[0] = x + front; A.x0[0] = x0 + front; A.xn[0] = xn + front; A.b[0] = 0; A.a = 0.3f; A.inv = 1.0f / 2.8f;
-    A.x0out[0] = xn + front; A.dt = 0.1f;
+    A.x0out[0] = xn + front; A.dt = (T)0.1f;
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     float best = 1e30f;
@@ -95,8 +99,8 @@ void run(int N, const char* what, int gx, int gy, int gz_override) {
         std::vector<T> h((size_t)(front + elems + back));
         CK(hipMemcpy(h.data(), xn, bytes, hipMemcpyDeviceToHost));
         for (size_t q = (size_t)front; q < (size_t)(front + elems); ++q) {  // (the field itself, not its padding)
-            unsigned u;
-            memcpy(&u, &h[q], 4);
+            unsigned long long u = 0;
+            memcpy(&u, &h[q], sizeof(T));
             sum_bits = (sum_bits ^ u) * 1099511628211ull;
         }
     }
