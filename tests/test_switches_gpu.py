@@ -36,8 +36,7 @@ SWITCHES = [
 # SF_TRACE_SCHEDULE: tests/test_schedule_trace.py)
 
 
-def run_case(N, P, K, steps, transport="copy"):
-    dtype = np.float32
+def run_case(N, P, K, steps, transport="copy", dtype=np.float32):
     f = small_velocity(rand_fields(N, dtype, 300 + N + P), N, dtype)
     src = {n: f[n].copy() for n in ("u0", "v0", "w0", "dens0")}
     kw = {"nslabs_local": P}
@@ -73,3 +72,15 @@ def test_switch_settings_against_the_oracle(env, monkeypatch):
         got, want = run_case(N, P, K, steps, transport)
         for n in got:
             assert_same(got[n], want[n], f"{env} N={N} P={P} K={K} {transport}: {n}")
+
+
+@pytest.mark.parametrize("sweeps", ["2", "3"])
+def test_two_and_three_sweep_marching_fp64(sweeps, monkeypatch):
+    """The S = 2 / S = 3 instantiations of the marching kernel in fp64 (four-slot rings instead of shift registers: the
+    k-wall planes of round 3 sit in different slots there), one slab and three, against the oracle."""
+    monkeypatch.setenv("SF_SK_S", sweeps)
+    monkeypatch.setenv("SF_MARCH_MINCELLS_K", "100")
+    for N, P, K, steps, transport in ((64, 1, 7, 2, "copy"), (96, 3, 20, 1, "copy"), (72, 1, 9, 1, "copy")):
+        got, want = run_case(N, P, K, steps, transport, dtype=np.float64)
+        for n in got:
+            assert_same(got[n], want[n], f"SK_S={sweeps} f64 N={N} P={P} K={K}: {n}")
