@@ -1591,15 +1591,20 @@ private:
     bool fields_in_one_grid() const { return P_ == 1 && split_ == INT_MAX && split_fields_ != 2 && batch_now_; }
     // ... which the solve only asks for when every pass is a four-sweep marching launch (K a multiple of four on a
     // grid the kernel takes): a pair-kernel pass over three fields at once would leave the Infinity Cache. And only
-    // where it was measured to pay (same-box A/B of the full step, fields apart / in one grid): 256^3 2.17 / 2.09 ms,
-    // 512^3 K = 40 25.64 / 25.35; not at 160^3 (0.846 / 0.881: one field's three arrays sit in L2 + Infinity Cache
-    // there), not at 1024^3 (121.8 / 123.5) or 512^3 fp64 (49.6 / 49.8), whose chunks are long anyway.
+    // where it was measured to pay (same-box A/B of the full fp32 K = 20 step, ms, fields apart / in one grid; `one` =
+    // x + x0 + x' of one field): 160^3 (52 MB) 0.846 / 0.881; 192^3 (89 MB) 1.666 / 1.506; 208^3 (113 MB) 1.399 / 1.281;
+    // 224^3 (141 MB) 1.960 / 2.069 — one field still fits the 256 MiB Infinity Cache there, three do not —; 256^3 (201 MB)
+    // 2.17 / 2.09; 320^3 3.95 / 3.92; 384^3 6.59 / 6.54; 512^3 K = 40 25.64 / 25.35; 1024^3 121.8 / 123.5 and 512^3 fp64
+    // 49.6 / 49.8 (chunks are long anyway); fp64: 144^3 (76 MB) 1.579 / 1.409; 176^3 (137 MB) 2.048 / 2.162; 192^3
+    // (178 MB) 2.662 / 2.646; 256^3 (403 MB) 4.60 / 4.32; 320^3 7.89 / 7.75. Hence two windows in bytes, whatever the
+    // precision: 75..125 MB and 170 MB..2 GB.
     bool batch_march(int K, bool continued) const {
         if (!(P_ == 1 && split_fields_ != 2 && K % 4 == 0 && K >= 4 && sk_first_ && march_k_ != 0 && sk_s_ >= 4 &&
               can_fuse2() && ishell_skip_ && nzl_ >= march_min_planes_ && (long)N_ * N_ * nzl_ >= march_min_cells_))
             return false;
         const double one = 3.0 * (double)(N_ + 2) * (N_ + 2) * nplanes_ * sizeof(T);  // x, x0, x' of one field
-        if (split_fields_ == 1 && (one < 96.0 * 1048576.0 || one > 2048.0 * 1048576.0)) return false;
+        const double mb = one / 1048576.0;
+        if (split_fields_ == 1 && !((mb >= 75.0 && mb <= 125.0) || (mb >= 170.0 && mb <= 2048.0))) return false;
         return continued || K >= 8;
     }
 
