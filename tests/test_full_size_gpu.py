@@ -70,6 +70,28 @@ def test_mid_size_default_thresholds():
         assert fs.lin_solve_launches(20) == 5  # five four-sweep marching launches, no pair launch
 
 
+def test_fields_in_one_grid_default_thresholds_caller_sources():
+    """192^3 fp32, K = 20, default switches, sources uploaded by the caller (no bind_sources): one field's x + x0 + x' take
+    89 MB, inside the first window of Solver::batch_march, so u, v, w are diffused as ONE marching grid — add_source as its
+    own kernel, one caller-data first pass per field, then plain passes over the three fields. One step against the
+    oracle (test_config2_full_size covers the bound-source form at 256^3, in the second window)."""
+    N, K, dtype = 192, 20, np.float32
+    f, src = bench_state(N, dtype)
+    with make(N, dtype, K=K) as fs:
+        for n in ("u", "v", "w", "dens"):
+            fs.upload(n, f[n])
+        for n in src:
+            fs.upload(n, src[n])
+        fs.vel_step()
+        fs.dens_step()
+        fs.sync()
+        got = {n: fs.download(n) for n in ("u", "v", "w", "dens")}
+    f.update({n: src[n].copy() for n in src})
+    O.step(N, f, dtype(DT), dtype(DIFF), dtype(VISC), K)
+    for n in got:
+        assert_same(got[n], f[n], f"192^3 f32 K=20, caller sources, default thresholds: {n}")
+
+
 def roofline_inputs(N, dtype):
     """The inputs of bench.py's roofline leg (time_lin_solve): one random plane scaled per k."""
     rng = np.random.RandomState(1)
