@@ -82,7 +82,7 @@ public:
         // three / four ghost planes where the marching kernel will run three / four sweeps per pass on the slab
         // interiors (one exchange per pass): the interior launch [2G, nzl) must be long and large enough for it
         {
-            const long min_cells = (long)env_int("SF_MARCH_MINCELLS_K", 6000) * 1000L;
+            const long min_cells = (long)env_int("SF_MARCH_MINCELLS_K", 2500) * 1000L;  // (march_min_cells_, below)
             const int ghost_max = env_int("SF_GHOST", 4), smax = env_int("SF_SK_S", 4);
             for (int gs = 3; gs <= 4; ++gs) {  // S = gs sweeps per exchange need gs ghost planes
                 const int interior = nzl_ - 2 * gs;
@@ -185,11 +185,11 @@ public:
         graphs_ = env_int("SF_GRAPH", 0) != 0 && P_ == 1;
         march_k_ = env_int("SF_MARCH", 1);  // 0: the register-blocked pair kernel everywhere
         march_min_planes_ = env_int("SF_MARCH_MINP", 12);
-        // Smallest launch the marching kernel takes. Slab interiors: 6 M cells (~182^3 worth; thin slabs pay chunk ends).
-        // Undecomposed grids: 2.5 M (~136^3) — with 16 thin waves per workgroup it overtakes the pair kernel there
-        // (us per sweep of a 20-sweep solve, pair / marching: 128^3 4.4 / 5.8, 144^3 9.0 / 6.0, 160^3 10.6 / 6.3,
-        // 176^3 13.4 / 7.1). SF_MARCH_MINCELLS_K sets both.
-        march_min_cells_ = (long)env_int("SF_MARCH_MINCELLS_K", P_ == 1 ? 2500 : 6000) * 1000L;
+        // Smallest launch the marching kernel takes: 2.5 M cells (~136^3; 6 M until round 3) — with 16 thin waves per
+        // workgroup it overtakes the pair kernel there (us per sweep of a 20-sweep solve, pair / marching: 128^3 4.4 /
+        // 5.8, 144^3 9.0 / 6.0, 160^3 10.6 / 6.3, 176^3 13.4 / 7.1), slab interiors included (one rank's share of the
+        // full step: 256^3 over 4 ranks 1.335 -> 1.147 ms, 384^3 over 8 ranks 1.806 -> 1.492).
+        march_min_cells_ = (long)env_int("SF_MARCH_MINCELLS_K", 2500) * 1000L;
         sk2_min_cells_ = std::max(march_min_cells_ == 0 ? 0L : 60000000L, march_min_cells_);  // ~390^3
         sk_s_ = env_int("SF_SK_S", 4);
         sk_first_ = env_int("SF_SK_FIRST", 1) != 0;  // first pass of a solve through the marching kernel
@@ -2106,7 +2106,7 @@ private:
     bool ishell_skip_ = true, zero_skip_ = true, x_is_zero_ = false, fuse_src_ = true;
     bool fuse2_ = true;
     int march_k_ = 1, march_min_planes_ = 12;
-    long march_min_cells_ = 6000000, sk2_min_cells_ = 60000000;
+    long march_min_cells_ = 2500000, sk2_min_cells_ = 60000000;
     int sk_s_ = 4;
     bool sk_first_ = true;
     bool batch_now_ = false;  // the running solve launches its NF fields as one marching grid (batch_march)

@@ -37,7 +37,7 @@ def main():
     kb, ke = sfdist.slab_planes(N, rank, world)
     assert ke - kb == N // world and sfdist.stored_planes(N, rank, world) == (kb - 1, ke + 1)
     mode = sys.argv[5] if len(sys.argv) > 5 else "g1"
-    mincells_k = int(sys.argv[6]) if len(sys.argv) > 6 else 6000
+    mincells_k = int(sys.argv[6]) if len(sys.argv) > 6 else 2500
     bound = len(sys.argv) > 7 and sys.argv[7] == "1"
     trace = sys.argv[8] if len(sys.argv) > 8 else None
 

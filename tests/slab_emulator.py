@@ -32,8 +32,8 @@ class Schedule:
         self.wsize = wsize
         self.nzl = N // P
         self.march, self.sk_s, self.sk_first, self.ishell = march, sk_s, sk_first, ishell
-        if march_mincells_k is None:  # the library's default: 2.5 M cells on one slab, 6 M on a decomposed grid
-            march_mincells_k = 2500 if P == 1 else 6000
+        if march_mincells_k is None:  # the library's default: 2.5 M cells
+            march_mincells_k = 2500
         self.split, self.minp, self.mincells = split, march_minp, march_mincells_k * 1000
         self.sk2_mincells = max(60000000 if self.mincells else 0, self.mincells)
         self.fuse2, self.fuse_src, self.zero_skip, self.split_fields = fuse2, fuse_src, zero_skip, split_fields

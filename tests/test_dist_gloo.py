@@ -41,9 +41,9 @@ PROD_CASES = [
     (2, 64, 11, "f32", 10, "1"),   # nzl 32: G = 4, first pass 4 (folded source) + 4 + 3
     (2, 64, 20, "f32", 10, "0"),   # G = 4, 4 + 4 x 4
     (4, 96, 9, "f32", 10, "1"),    # nzl 24: G = 4, bound sources: first pass 4 (folded) + 3 + 2
-    (4, 32, 6, "f64", 6000, "1"),  # default thresholds: G = 2, pairs only
+    (4, 32, 6, "f64", 2500, "1"),  # default thresholds: G = 2, pairs only
     (2, 40, 5, "f64", 10, "0"),    # nzl 20: G = 4 (interior 12), odd K below the first-pass threshold: 2 + 3
-    (2, 12, 4, "f32", 6000, "1"),  # thin slabs (nzl 6): G = 2
+    (2, 12, 4, "f32", 2500, "1"),  # thin slabs (nzl 6): G = 2
     (2, 36, 8, "f32", 10, "1"),    # nzl 18: G = 3 (interior 12; four ghost planes would leave 10), pair + 3 + 3
 ]
 
